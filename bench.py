@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- M ray-samples/s of the fused sample+encode+MLP+composite renderer.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+Workload (BASELINE.json metric): synthetic 800x800 camera frames, 64 samples per ray, the 8x256
+NeRF MLP (nerf_model.NeRFMLP, 951 808 FLOP per ray-sample), deterministic random-init weights
+("fog" scene: no ray saturates; early ray termination OFF), bf16 MFMA.  One step renders
+n_gpus frames: every frame's rays are sharded by contiguous pixel band over the ranks (rank r
+renders rays [r*HW/N, (r+1)*HW/N) of every frame -> per-GPU work is one frame's worth of rays,
+weak scaling) and the finished bands are exchanged with ONE RCCL all_gather per step so that
+every rank holds all frames.  Inputs are generated in-kernel (camera mode): nothing is read
+from the host in the timed region.
+
+The JSON line also carries
+  roofline     -- algorithmic FLOPs of the render kernel / its mean launch duration (HIP events on
+                  the launch stream) against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline -- the CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch CPU
+                  path) timed on a band of rows of the same frame on this host's cores;
+  parity       -- max abs error / PSNR of the benchmarked mode vs that oracle band.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=800)
+    ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--net", default="v1", choices=["v1", "v2"])
+    ap.add_argument("--scene", default="fog", choices=["fog", "solid"])
+    ap.add_argument("--ert", type=float, default=0.0)
+    ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import nerf_few_shot_limitations_amd as N
+    from oracle import nerf_oracle as O               # cpu_baseline / parity legs only
+
+    H, W, S = args.height, args.width, args.samples
+    c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
+    focal = O.focal_for(W)
+    seed = 0 if args.net == "v1" else 1
+    p = O.make_weights(args.net, seed, args.scene)
+    if args.net == "v1":
+        model = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=args.mode)
+        model.load_state_dict(p)
+    else:
+        model = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=args.mode)
+        model.load_state_dict(p, strict=False)
+    model = model.to(dev).eval()
+    flops_per_sample = model.flops_per_sample()
+
+    n_frames = world
+    band = (H * W + world - 1) // world               # rays of each frame this rank renders
+    b0 = rank * band
+    b1 = min(b0 + band, H * W)
+    local = torch.zeros((n_frames, band, 4), dtype=torch.float32, device=dev)       # rgb + depth per ray
+    rgb_buf = torch.empty((band, 3), dtype=torch.float32, device=dev)
+    depth_buf = torch.empty((band,), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world, n_frames, band, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    ev = []
+
+    def step(timed):
+        for f in range(n_frames):
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=b0, ray_end=b1, ert_eps=args.ert,
+                            device=dev, out_rgb=rgb_buf[: b1 - b0], out_depth=depth_buf[: b1 - b0])
+            if timed:
+                e1.record()
+                ev.append((e0, e1))
+            local[f, : b1 - b0, :3] = rgb_buf[: b1 - b0]
+            local[f, : b1 - b0, 3] = depth_buf[: b1 - b0]
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+    samples_per_launch = (b1 - b0) * S
+    samples_per_step = n_frames * H * W * S                     # all ranks together
+    value = samples_per_step * args.steps / dt / 1e6
+    achieved = samples_per_launch * flops_per_sample / (kernel_ms * 1e-3) / 1e12
+
+    out = {
+        "metric": "M ray-samples/sec (sample+MLP+composite) at 800^2x64",
+        "value": round(value, 2), "unit": "M ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.mode, "data": "synthetic",
+        "config": {"workload": f"{H}x{W} camera frame x {S} samples/ray, NeRFMLP {args.net} 8x256, scene {args.scene}, "
+                               f"{n_frames} frame(s)/step band-sharded over {world} GPU(s) + all_gather",
+                   "rays_per_gpu_per_step": n_frames * (b1 - b0), "samples_per_ray": S, "ert_eps": args.ert,
+                   "flops_per_sample": flops_per_sample, "parallelism": f"pixel-band x{world}"},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.mode], "unit": "TFLOP/s",
+                     "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": None,
+                     "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ev)},
+    }
+
+    if rank == 0 and world == 1 and args.cpu_rows > 0:
+        # CPU oracle on a band of rows of the same frame (port of the reference's torch-CPU path)
+        threads = os.cpu_count() or 1
+        torch.set_num_threads(threads)
+        rows = min(args.cpu_rows, H)
+        r0 = (H // 2) * W
+        r1 = r0 + rows * W
+        ro, rd = O.get_rays(H, W, focal, c2w)
+        ro, rd = ro.reshape(-1, 3)[r0:r1].contiguous(), rd.reshape(-1, 3)[r0:r1].contiguous()
+        best = None
+        ref = None
+        for _ in range(3):
+            tc = time.perf_counter()
+            ref = O.render_rays(p, args.net, ro, rd, 2.0, 6.0, S, chunk=2048)
+            el = time.perf_counter() - tc
+            best = el if best is None else min(best, el)
+        out["cpu_baseline"] = {"value": round(rows * W * S / best / 1e6, 4), "unit": "M ray-samples/s", "cores": threads,
+                               "kind": "port", "sample": f"{rows} rows ({rows * W} rays x {S} samples) of the same {H}x{W} frame, "
+                                                          f"torch fp32 CPU, chunk 2048 rays, best of 3"}
+        rgb_b, depth_b = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, ert_eps=args.ert, device=dev)
+        rgb32, depth32 = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f32", device=dev)
+        torch.cuda.synchronize()
+        out["parity"] = {
+            "band_rows": rows,
+            f"{args.mode}_max_abs_rgb": float((rgb_b.cpu() - ref["rgb"]).abs().max()),
+            f"{args.mode}_max_abs_depth": float((depth_b.cpu() - ref["depth"]).abs().max()),
+            f"{args.mode}_psnr_vs_oracle_db": round(O.psnr(rgb_b.cpu(), ref["rgb"]), 2),
+            "f32_max_abs_rgb": float((rgb32.cpu() - ref["rgb"]).abs().max()),
+            "f32_max_abs_depth": float((depth32.cpu() - ref["depth"]).abs().max()),
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,178 @@
+/* nerfhip.h -- C ABI of libnerfhip.so, the MI355X (gfx950) renderer for the
+ * ray-marching hot path of ANKITSANJYAL/nerf-few-shot-limitations.
+ *
+ * The reference has no FFI of its own (it is 100 % Python, SURVEY.md section
+ * 8b): the "interface each entry point replaces" is therefore the Python
+ * callable named next to it (paths relative to the reference root).  The
+ * Python package nerf_few_shot_limitations_amd binds this header with ctypes;
+ * INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative NRF_E* code; the
+ *     message is kept per thread and read with nrf_last_error();
+ *   - no C++ exception crosses the boundary;
+ *   - the CALLER owns every buffer (device pointers unless stated "host");
+ *     the library owns only the packed weight copies inside a nrf_model;
+ *   - all work is enqueued on the caller's stream (void* = hipStream_t,
+ *     NULL = the default stream); nothing synchronises, nothing allocates on
+ *     a render / staged call;
+ *   - all tensors are contiguous fp32, row-major, in the reference's layouts;
+ *     ray id r = y*W + x (row-major pixel order) is the integer contract.
+ */
+#ifndef NERFHIP_H
+#define NERFHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRF_ABI_VERSION 1
+
+/* error codes */
+#define NRF_OK            0
+#define NRF_EINVAL       -1   /* bad argument (shape, null pointer, unsupported size) */
+#define NRF_EUNSUPPORTED -2   /* architecture / mode not built into this library */
+#define NRF_EHIP         -3   /* a HIP runtime call failed */
+#define NRF_ENOMEM       -4
+
+/* network families on the path */
+#define NRF_NET_V1 1  /* src/models/nerf_model.py:5-24  NeRFMLP(pos_dim=63,hidden,n_layers): PE(10) -> 8x(Linear+ReLU) -> sigma | sigmoid rgb */
+#define NRF_NET_V2 2  /* src/models/nerf_mlp.py:41-84   PE(pos) -> DensityMLP -> ColorMLP(feature, PE(dir)): train.py:82-89 with use_dino=False */
+#define NRF_NET_V3 3  /* src/models/nerf_mlp.py:86-158  NeRFWithDINO: + lora_dino.py:146-193 NeRFDINOFusion */
+
+/* arithmetic of the MLP contraction (accumulation is always fp32) */
+#define NRF_MMA_BF16 0  /* v_mfma_f32_32x32x16_bf16: weights + activations rounded to bf16 (throughput mode) */
+#define NRF_MMA_F16  1  /* v_mfma_f32_32x32x16_f16 : same rate, 3 more mantissa bits                          */
+#define NRF_MMA_F32  2  /* v_mfma_f32_32x32x2_f32  : exact fp32 fma chain (parity mode, 1/16 rate)           */
+
+typedef struct nrf_model nrf_model;
+
+typedef struct nrf_arch {
+    int32_t net;        /* NRF_NET_* */
+    int32_t pos_freq;   /* L of the position encoding (10 -> 63 features, 12 -> 75) */
+    int32_t dir_freq;   /* L of the direction encoding (V2/V3; 4 -> 27 features)   */
+    int32_t hidden;     /* hidden width (256)                                       */
+    int32_t n_layers;   /* number of Linear+ReLU layers of the trunk (8)            */
+    int32_t dino_dim;   /* feature-map channels (V3; 64)                            */
+} nrf_arch;
+
+/* One nn.Linear, HOST pointers, weight (out_f,in_f) row-major and bias (out_f),
+ * in the order of the module's state_dict:
+ *   V1: layers.0 .. layers.{n-1}, sigma_out, rgb_out                        (nerf_model.py:8-14)
+ *   V2: density_mlp.density_layers.{0,2,..}, density_head, feature_head,
+ *       color_mlp.color_layers.{0,2,4}                                      (nerf_mlp.py:46-57,72-79)
+ *   V3: dino_fusion.fusion.{0,2}, dino_fusion.attention.{0,2},
+ *       dino_fusion.output_proj, then the V2 list                           (lora_dino.py:153-169) */
+typedef struct nrf_linear {
+    const float* weight;
+    const float* bias;
+    int32_t out_f;
+    int32_t in_f;
+} nrf_linear;
+
+/* DINO side channel of V3 (train.py:203-214): the feature map of ONE source
+ * view, its camera and intrinsics. */
+typedef struct nrf_dino {
+    const float* features;   /* device, (1,Hp,Wp,C) fp32, channel-last (dino_feature_model.py:114-148) */
+    int32_t Hp, Wp, C;
+    float   inv_pose[16];    /* inverse of the source view's 4x4 camera-to-world, row-major (ray_utils.py:191) */
+    float   focal;
+    int32_t H, W;            /* image size the projection normalises by (ray_utils.py:199-204) */
+} nrf_dino;
+
+typedef struct nrf_render_opts {
+    float    near, far;      /* train.py:192-193                                                      */
+    int32_t  n_samples;      /* S                                                                     */
+    int32_t  lindisp;        /* ray_utils.py:59-62                                                    */
+    int32_t  perturb;        /* 1: stratified jitter (ray_utils.py:71-79)                             */
+    const float* t_rand;     /* device (R,S) U[0,1) jitter, or NULL -> in-kernel counter RNG(rng_seed) */
+    uint64_t rng_seed;
+    float    ert_eps;        /* early ray termination: stop a wave once every live ray has T < eps; 0 = off (reference behaviour) */
+    int32_t  white_bkgd;     /* nerf_mlp.py:209-212                                                   */
+    int32_t  mma_mode;       /* NRF_MMA_*                                                             */
+    const nrf_dino* dino;    /* V3 only (host struct, copied at launch)                               */
+} nrf_render_opts;
+
+/* ---- model handle -------------------------------------------------------- */
+
+/* Build the device-side packed weight streams (all three NRF_MMA_* modes) for
+ * `arch` from `n_linear` host Linear layers.  Replaces: module construction +
+ * .to(device), train.py:82-89 / nerf_model.py:6-14. */
+int nrf_model_create(nrf_model** out, int device, const nrf_arch* arch,
+                     const nrf_linear* linears, int n_linear);
+/* Re-pack after the weights changed (optimizer.step / load_state_dict). */
+int nrf_model_update(nrf_model* m, const nrf_linear* linears, int n_linear, void* stream);
+void nrf_model_destroy(nrf_model* m);
+/* 2*MAC of the Linear layers per ray-sample. */
+int64_t nrf_model_flops_per_sample(const nrf_model* m);
+
+/* ---- the fused path -------------------------------------------------------- */
+
+/* sample -> encode -> MLP -> composite for explicit rays.
+ * Replaces NeRFDINOTrainer.render_rays, train.py:188-242.
+ * rays_o, rays_d: (R,3).  Outputs: rgb (R,3), depth (R); weights (R,S) and
+ * z_vals (R,S) may be NULL. */
+int nrf_render_rays(const nrf_model* m, const float* rays_o, const float* rays_d, int64_t n_rays,
+                    const nrf_render_opts* opts,
+                    float* rgb, float* depth, float* weights, float* z_vals, void* stream);
+
+/* Same, with the rays generated in-kernel from a pinhole camera
+ * (ray_sampler.py:4-30) for the ray-id range [ray_begin, ray_end) of an HxW
+ * image; output row i holds ray ray_begin+i.  c2w = first 3 rows of the pose,
+ * row-major, host.  Replaces get_rays + the eval chunk loop, train.py:305-319 /
+ * evaluate.py:65-81. */
+int nrf_render_camera(const nrf_model* m, int H, int W, float focal, const float c2w[12],
+                      int64_t ray_begin, int64_t ray_end, const nrf_render_opts* opts,
+                      float* rgb, float* depth, float* weights, float* z_vals, void* stream);
+
+/* ---- staged entry points (one reference leaf each; used by the drop-in
+ *      Python surface and by the stage-wise parity tests) ------------------- */
+
+/* ray_sampler.py:4-30 == ray_utils.py:4-37.  Rays [ray_begin,ray_end) -> (n,3),(n,3). */
+int nrf_get_rays(int H, int W, float focal, const float c2w[12], int64_t ray_begin, int64_t ray_end,
+                 float* rays_o, float* rays_d, void* stream);
+/* ray_utils.py:39-84 == ray_sampler.py:32-61.  pts (R,S,3) and/or z_vals (R,S) (either may be NULL). */
+int nrf_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays,
+                          float near, float far, int n_samples, int lindisp, int perturb,
+                          const float* t_rand, uint64_t rng_seed,
+                          float* pts, float* z_vals, void* stream);
+/* positional_encoding.py:20-33 == nerf_mlp.py:17-33.  x (n,dim) -> out (n, dim*(2L+include_input)). */
+int nrf_encode(const float* x, int64_t n, int dim, int num_freqs, int include_input, float* out, void* stream);
+/* V1: nerf_model.py:16-24, x_enc (P, 3*(2*pos_freq+1)) -> out4 (P,4) = [rgb, sigma]. */
+int nrf_mlp_forward_v1(const nrf_model* m, int mma_mode, const float* x_enc, int64_t n, float* out4, void* stream);
+/* V2/V3: NeRFMLP.forward(positions, directions, dino_features), train.py:229 / nerf_mlp.py:134-158:
+ * positions (P,3), directions (P,3), dino (P,dino_dim) or NULL (V2) -> rgb (P,3), density (P,1). */
+int nrf_mlp_forward(const nrf_model* m, int mma_mode, const float* positions, const float* directions,
+                    const float* dino, int64_t n, float* rgb, float* density, void* stream);
+/* nerf_mlp.py:165-215 (VolumeRenderer.forward, eval path) and volume_renderer.py:4-43:
+ * rgb (R,S,*) with element stride rgb_stride (3, or 4 for the [r,g,b,sigma] layout),
+ * sigma (R,S,*) with stride sigma_stride (1 or 4).  out_depth / out_weights may be NULL. */
+int nrf_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride,
+                  const float* z_vals, const float* rays_d, int64_t n_rays, int n_samples, int white_bkgd,
+                  float* out_rgb, float* out_depth, float* out_weights, void* stream);
+/* ray_utils.py:86-143 (intent; the reference function raises):
+ * z_vals, weights (R,S) -> samples (R,Ni) and sorted union (R,S+Ni); u (R,Ni) or NULL -> linspace(0,1,Ni). */
+int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance,
+                   const float* u, float* samples, float* z_union, void* stream);
+/* ray_utils.py:176-210 + dino_feature_model.py:114-148: points (N,3) -> features (N,C); xy (N,2) may be NULL. */
+int nrf_project_fetch(const nrf_dino* dino, const float* points, int64_t n, float* feats, float* xy, void* stream);
+
+/* ---- host-only introspection (no GPU needed; used by the CPU test-suite to replay the
+ *      kernel's MFMA walk over the packed stream) -------------------------------- */
+/* Packs `linears` exactly as nrf_model_create would for `mma_mode`.  stream_out / bias_out may be
+ * NULL to query the sizes (bytes of the fragment stream, floats of the bias table). */
+int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int mma_mode,
+                   uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes,
+                   float* bias_out, int64_t bias_cap, int64_t* n_bias);
+
+/* ---- misc ------------------------------------------------------------------ */
+const char* nrf_last_error(void);
+int nrf_abi_version(void);
+/* name / average duration bookkeeping is the caller's business: the library never times anything. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFHIP_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of libnerfhip.so (include/nerfhip.h).
+
+The library is the product: there is no Python / PyTorch fallback.  If it is
+missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch  # imported BEFORE the library on purpose: libnerfhip.so then binds to the HIP runtime torch already loaded
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libnerfhip.so")
+
+NRF_NET_V1, NRF_NET_V2, NRF_NET_V3 = 1, 2, 3
+MMA_MODES = {"bf16": 0, "f16": 1, "f32": 2}
+ERRORS = {-1: "NRF_EINVAL", -2: "NRF_EUNSUPPORTED", -3: "NRF_EHIP", -4: "NRF_ENOMEM"}
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class NrfError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libnerfhip: {ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class nrf_arch(C.Structure):
+    _fields_ = [("net", C.c_int32), ("pos_freq", C.c_int32), ("dir_freq", C.c_int32), ("hidden", C.c_int32),
+                ("n_layers", C.c_int32), ("dino_dim", C.c_int32)]
+
+
+class nrf_linear(C.Structure):
+    _fields_ = [("weight", c_float_p), ("bias", c_float_p), ("out_f", C.c_int32), ("in_f", C.c_int32)]
+
+
+class nrf_dino(C.Structure):
+    _fields_ = [("features", C.c_void_p), ("Hp", C.c_int32), ("Wp", C.c_int32), ("C", C.c_int32),
+                ("inv_pose", C.c_float * 16), ("focal", C.c_float), ("H", C.c_int32), ("W", C.c_int32)]
+
+
+class nrf_render_opts(C.Structure):
+    _fields_ = [("near", C.c_float), ("far", C.c_float), ("n_samples", C.c_int32), ("lindisp", C.c_int32),
+                ("perturb", C.c_int32), ("t_rand", C.c_void_p), ("rng_seed", C.c_uint64), ("ert_eps", C.c_float),
+                ("white_bkgd", C.c_int32), ("mma_mode", C.c_int32), ("dino", C.POINTER(nrf_dino))]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_cabi.py checks against include/nerfhip.h
+SIGNATURES = {
+    "nrf_abi_version": (C.c_int, []),
+    "nrf_last_error": (C.c_char_p, []),
+    "nrf_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int]),
+    "nrf_model_update": (C.c_int, [C.c_void_p, C.POINTER(nrf_linear), C.c_int, C.c_void_p]),
+    "nrf_model_destroy": (None, [C.c_void_p]),
+    "nrf_model_flops_per_sample": (C.c_int64, [C.c_void_p]),
+    "nrf_render_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(nrf_render_opts),
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_render_camera": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float * 12, C.c_int64, C.c_int64,
+                                    C.POINTER(nrf_render_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_get_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float * 12, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_sample_along_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_mlp_forward_v1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nrf_mlp_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_composite": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_sample_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_debug_pack": (C.c_int, [C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                 C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
+    "nrf_project_fetch": (C.c_int, [C.POINTER(nrf_dino), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Load libnerfhip.so once.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m nerf_few_shot_limitations_amd.build` "
+                                   "(there is no fallback path)")
+            handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(handle, name)          # AttributeError if the symbol is not exported
+                fn.restype, fn.argtypes = res, args
+            if handle.nrf_abi_version() != 1:
+                raise RuntimeError("libnerfhip.so ABI version mismatch")
+            _lib = handle
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise NrfError(code, lib().nrf_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t):
+    """Device pointer of a CUDA(HIP) fp32 contiguous tensor, or None."""
+    if t is None:
+        return None
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError("expected a contiguous float32 tensor on the GPU")
+    return C.c_void_p(t.data_ptr())
+
+
+def dev_f32(t, device=None):
+    """Bring a tensor-like to contiguous fp32 on the GPU (the reference's callers hand over fp32 tensors)."""
+    t = torch.as_tensor(t)
+    if device is None:
+        device = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("nerf_few_shot_limitations_amd needs an MI355X (gfx950) GPU: no HIP device is visible and there is no CPU path")

@@ -1,0 +1,76 @@
+"""Build libnerfhip.so (gfx950) in-tree with hipcc.
+
+    python -m nerf_few_shot_limitations_amd.build [--force]
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build
+container; the resulting .so (git-ignored) travels to the GPU box with the
+repository snapshot.  There is exactly one target architecture and no fallback.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import os
+import shutil
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+OBJ = os.path.join(PKG, "build")
+LIB = os.path.join(PKG, "libnerfhip.so")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")
+
+SOURCES = ["fused_kernels.hip", "staged_kernels.hip", "api.cpp", "packing.cpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
+         "-fno-gpu-rdc", f"-I{INCLUDE}"]
+
+
+def hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: libnerfhip.so cannot be built (ROCm toolchain required)")
+    return exe
+
+
+def _newest(paths):
+    return max(os.path.getmtime(p) for p in paths)
+
+
+def _deps():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(INCLUDE, "nerfhip.h")]
+
+
+def _compile(src: str, verbose: bool) -> str:
+    obj = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+    cmd = [hipcc(), *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+    if verbose and r.stderr.strip():
+        print(r.stderr, file=sys.stderr)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile (if stale) and return the path of libnerfhip.so."""
+    deps = _deps()
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
+        return LIB
+    os.makedirs(OBJ, exist_ok=True)
+    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, verbose), SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose=True)
+    print(path)

@@ -1,0 +1,343 @@
+// api.cpp -- the extern "C" surface of libnerfhip.so (include/nerfhip.h).
+// Argument checking happens here, on the host, before any kernel is launched: a
+// launch only goes out once every shape the kernel and its grid assume has been
+// verified.  No C++ exception leaves this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/nerfhip.h"
+#include "kernels.hpp"
+#include "packing.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    return fail(NRF_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define NRF_HIP(call)                                    \
+    do {                                                 \
+        const hipError_t e_ = (call);                    \
+        if (e_ != hipSuccess) return hip_fail(e_, #call); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) return;
+        ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+bool copy_linears(const nrf_linear* in, int n, std::vector<nrf::HostLinear>& out, std::string& err) {
+    out.resize(n);
+    for (int i = 0; i < n; ++i) {
+        if (!in[i].weight || !in[i].bias || in[i].out_f <= 0 || in[i].in_f <= 0) {
+            err = "linear " + std::to_string(i) + ": null pointer or non-positive shape";
+            return false;
+        }
+        out[i].out_f = in[i].out_f;
+        out[i].in_f = in[i].in_f;
+        out[i].w.assign(in[i].weight, in[i].weight + (size_t)in[i].out_f * in[i].in_f);
+        out[i].b.assign(in[i].bias, in[i].bias + in[i].out_f);
+    }
+    return true;
+}
+
+nrf::Camera make_camera(int H, int W, float focal, const float c2w[12]) {
+    nrf::Camera c;
+    c.H = H; c.W = W; c.focal = focal;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) c.r[i][j] = c2w[4 * i + j];
+        c.t[i] = c2w[4 * i + 3];
+    }
+    return c;
+}
+
+bool make_dino(const nrf_dino* in, int want_c, nrf::DinoDev& d, std::string& err) {
+    if (!in || !in->features) { err = "dino side channel missing (features == NULL)"; return false; }
+    if (in->Hp < 1 || in->Wp < 1 || in->C < 1 || in->H < 1 || in->W < 1) { err = "dino: bad map / image size"; return false; }
+    if (want_c > 0 && in->C != want_c) { err = "dino: channel count differs from the model's dino_dim"; return false; }
+    d.features = in->features; d.Hp = in->Hp; d.Wp = in->Wp; d.C = in->C;
+    std::memcpy(d.inv_pose, in->inv_pose, sizeof(float) * 12);
+    d.focal = in->focal; d.H = in->H; d.W = in->W;
+    return true;
+}
+
+}  // namespace
+
+struct nrf_model {
+    nrf_arch arch{};
+    int device = 0;
+    nrf::NetPlan plan;
+    std::vector<nrf::HostLinear> lin;
+    nrf::PackedStream h_stream[3];
+    std::vector<float> h_bias;
+    void* d_stream[3] = {nullptr, nullptr, nullptr};
+    float* d_bias = nullptr;
+    nrf::DeviceNet net{};
+};
+
+namespace {
+
+int upload(nrf_model* m, hipStream_t s, bool allocate) {
+    for (int mode = 0; mode < 3; ++mode) {
+        m->h_stream[mode] = nrf::pack_stream(m->plan, m->lin, mode);
+        const size_t bytes = m->h_stream[mode].bytes.size();
+        if (allocate) NRF_HIP(hipMalloc(&m->d_stream[mode], bytes));
+        NRF_HIP(hipMemcpyAsync(m->d_stream[mode], m->h_stream[mode].bytes.data(), bytes, hipMemcpyHostToDevice, s));
+        m->net.stream[mode] = m->d_stream[mode];
+        m->net.n_chunks[mode] = m->h_stream[mode].n_chunks;
+    }
+    m->h_bias = nrf::pack_bias(m->plan, m->lin);
+    if (allocate) NRF_HIP(hipMalloc((void**)&m->d_bias, m->h_bias.size() * sizeof(float)));
+    NRF_HIP(hipMemcpyAsync(m->d_bias, m->h_bias.data(), m->h_bias.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    NRF_HIP(hipStreamSynchronize(s));     // pageable staging: the host vectors may be re-packed right after
+    m->net.bias = m->d_bias;
+    m->net.n_bias = m->plan.n_bias;
+    m->net.flops_per_sample = m->plan.flops_per_sample;
+    return NRF_OK;
+}
+
+int check_opts(const nrf_render_opts* o) {
+    if (!o) return fail(NRF_EINVAL, "opts is NULL");
+    if (o->n_samples < 1 || o->n_samples > 4096) return fail(NRF_EINVAL, "n_samples must be in 1..4096");
+    if (!(o->near > 0.0f) || !(o->far > o->near) || !std::isfinite(o->far)) return fail(NRF_EINVAL, "need 0 < near < far");
+    if (o->mma_mode < 0 || o->mma_mode > 2) return fail(NRF_EINVAL, "unknown mma_mode");
+    if (!(o->ert_eps >= 0.0f) || o->ert_eps >= 1.0f) return fail(NRF_EINVAL, "ert_eps must be in [0,1)");
+    return NRF_OK;
+}
+
+void fill_common(nrf::RenderArgs& a, const nrf_render_opts* o, float* rgb, float* depth, float* weights, float* z_vals) {
+    a.near = o->near; a.far = o->far; a.n_samples = o->n_samples; a.lindisp = o->lindisp; a.perturb = o->perturb;
+    a.t_rand = o->perturb ? o->t_rand : nullptr; a.seed = o->rng_seed;
+    a.ert_eps = o->ert_eps; a.white_bkgd = o->white_bkgd;
+    a.rgb = rgb; a.depth = depth; a.weights = weights; a.z_vals = z_vals;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrf_abi_version(void) { return NRF_ABI_VERSION; }
+
+const char* nrf_last_error(void) { return g_err.c_str(); }
+
+int nrf_model_create(nrf_model** out, int device, const nrf_arch* arch, const nrf_linear* linears, int n_linear) {
+    if (!out || !arch || !linears || n_linear <= 0) return fail(NRF_EINVAL, "nrf_model_create: null argument");
+    *out = nullptr;
+    nrf_model* m = new (std::nothrow) nrf_model();
+    if (!m) return fail(NRF_ENOMEM, "out of host memory");
+    m->arch = *arch;
+    m->device = device;
+    std::string err;
+    if (!copy_linears(linears, n_linear, m->lin, err) || !nrf::make_plan(*arch, m->lin, m->plan, err)) {
+        delete m;
+        return fail(arch->net == NRF_NET_V3 ? NRF_EUNSUPPORTED : NRF_EINVAL, err);
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok) { delete m; return fail(NRF_EHIP, "cannot select device " + std::to_string(device)); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete m; return fail(NRF_EHIP, "hipGetDeviceProperties failed"); }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        delete m;
+        return fail(NRF_EUNSUPPORTED, std::string("libnerfhip is built for gfx950 only, device is ") + prop.gcnArchName);
+    }
+    m->net.arch = *arch;
+    m->net.device = device;
+    m->net.cu_count = prop.multiProcessorCount;
+    const int rc = upload(m, nullptr, true);
+    if (rc != NRF_OK) { nrf_model_destroy(m); return rc; }
+    *out = m;
+    return NRF_OK;
+}
+
+int nrf_model_update(nrf_model* m, const nrf_linear* linears, int n_linear, void* stream) {
+    if (!m || !linears) return fail(NRF_EINVAL, "nrf_model_update: null argument");
+    std::string err;
+    std::vector<nrf::HostLinear> lin;
+    nrf::NetPlan plan;
+    if (!copy_linears(linears, n_linear, lin, err) || !nrf::make_plan(m->arch, lin, plan, err)) return fail(NRF_EINVAL, err);
+    m->lin.swap(lin);
+    m->plan = plan;
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    return upload(m, (hipStream_t)stream, false);
+}
+
+void nrf_model_destroy(nrf_model* m) {
+    if (!m) return;
+    DeviceGuard guard(m->device);
+    for (int i = 0; i < 3; ++i)
+        if (m->d_stream[i]) (void)hipFree(m->d_stream[i]);
+    if (m->d_bias) (void)hipFree(m->d_bias);
+    delete m;
+}
+
+int64_t nrf_model_flops_per_sample(const nrf_model* m) { return m ? m->plan.flops_per_sample : 0; }
+
+int nrf_render_rays(const nrf_model* m, const float* rays_o, const float* rays_d, int64_t n_rays, const nrf_render_opts* opts,
+                    float* rgb, float* depth, float* weights, float* z_vals, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (n_rays < 0) return fail(NRF_EINVAL, "n_rays < 0");
+    if (n_rays == 0) return NRF_OK;
+    if (!rays_o || !rays_d || !rgb || !depth) return fail(NRF_EINVAL, "nrf_render_rays: null ray or output pointer");
+    const int rc = check_opts(opts);
+    if (rc != NRF_OK) return rc;
+    if ((int64_t)opts->n_samples * n_rays > (int64_t)1 << 40) return fail(NRF_EINVAL, "ray-sample count too large");
+    nrf::RenderArgs a{};
+    a.rays_o = rays_o; a.rays_d = rays_d; a.camera_mode = 0; a.ray_begin = 0; a.n_rays = n_rays;
+    fill_common(a, opts, rgb, depth, weights, z_vals);
+    std::string err;
+    if (m->arch.net == NRF_NET_V3 && !make_dino(opts->dino, m->arch.dino_dim, a.dino, err)) return fail(NRF_EINVAL, err);
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    const int r = nrf::launch_render(m->net, opts->mma_mode, a, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_render_camera(const nrf_model* m, int H, int W, float focal, const float c2w[12], int64_t ray_begin, int64_t ray_end,
+                      const nrf_render_opts* opts, float* rgb, float* depth, float* weights, float* z_vals, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (H < 1 || W < 1 || !(focal > 0.0f) || !c2w) return fail(NRF_EINVAL, "bad camera");
+    if (ray_begin < 0 || ray_end < ray_begin || ray_end > (int64_t)H * W) return fail(NRF_EINVAL, "ray range outside the image");
+    if (ray_end == ray_begin) return NRF_OK;
+    if (!rgb || !depth) return fail(NRF_EINVAL, "nrf_render_camera: null output pointer");
+    const int rc = check_opts(opts);
+    if (rc != NRF_OK) return rc;
+    nrf::RenderArgs a{};
+    a.camera_mode = 1; a.cam = make_camera(H, W, focal, c2w); a.ray_begin = ray_begin; a.n_rays = ray_end - ray_begin;
+    fill_common(a, opts, rgb, depth, weights, z_vals);
+    std::string err;
+    if (m->arch.net == NRF_NET_V3 && !make_dino(opts->dino, m->arch.dino_dim, a.dino, err)) return fail(NRF_EINVAL, err);
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    const int r = nrf::launch_render(m->net, opts->mma_mode, a, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_get_rays(int H, int W, float focal, const float c2w[12], int64_t ray_begin, int64_t ray_end, float* rays_o, float* rays_d,
+                 void* stream) {
+    if (H < 1 || W < 1 || !(focal > 0.0f) || !c2w) return fail(NRF_EINVAL, "bad camera");
+    if (ray_begin < 0 || ray_end < ray_begin || ray_end > (int64_t)H * W) return fail(NRF_EINVAL, "ray range outside the image");
+    if (ray_end > ray_begin && (!rays_o || !rays_d)) return fail(NRF_EINVAL, "null output");
+    const int r = nrf::launch_get_rays(make_camera(H, W, focal, c2w), ray_begin, ray_end - ray_begin, rays_o, rays_d, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "get_rays launch failed");
+}
+
+int nrf_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, float near, float far, int n_samples, int lindisp,
+                          int perturb, const float* t_rand, uint64_t rng_seed, float* pts, float* z_vals, void* stream) {
+    if (n_rays < 0 || n_samples < 1) return fail(NRF_EINVAL, "bad sizes");
+    if (n_rays == 0) return NRF_OK;
+    if (!rays_o || !rays_d || (!pts && !z_vals)) return fail(NRF_EINVAL, "null pointer");
+    const int r = nrf::launch_sample(rays_o, rays_d, n_rays, near, far, n_samples, lindisp, perturb, perturb ? t_rand : nullptr, rng_seed,
+                                     pts, z_vals, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "sample launch failed");
+}
+
+int nrf_encode(const float* x, int64_t n, int dim, int num_freqs, int include_input, float* out, void* stream) {
+    if (n < 0 || dim < 1 || num_freqs < 0 || num_freqs > 31) return fail(NRF_EINVAL, "bad sizes");
+    if (n == 0) return NRF_OK;
+    if (!x || !out) return fail(NRF_EINVAL, "null pointer");
+    const int r = nrf::launch_encode(x, n, dim, num_freqs, include_input, out, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "encode launch failed");
+}
+
+int nrf_mlp_forward_v1(const nrf_model* m, int mma_mode, const float* x_enc, int64_t n, float* out4, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (n < 0) return fail(NRF_EINVAL, "n < 0");
+    if (n == 0) return NRF_OK;
+    if (!x_enc || !out4) return fail(NRF_EINVAL, "null pointer");
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    std::string err;
+    const int r = nrf::launch_forward_v1(m->net, mma_mode, x_enc, n, out4, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_mlp_forward(const nrf_model* m, int mma_mode, const float* positions, const float* directions, const float* dino, int64_t n,
+                    float* rgb, float* density, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (n < 0) return fail(NRF_EINVAL, "n < 0");
+    if (n == 0) return NRF_OK;
+    if (!positions || !directions || !rgb || !density) return fail(NRF_EINVAL, "null pointer");
+    if (m->arch.net == NRF_NET_V3 && !dino) return fail(NRF_EINVAL, "V3 needs dino features");
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    std::string err;
+    const int r = nrf::launch_forward(m->net, mma_mode, positions, directions, dino, n, rgb, density, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z_vals, const float* rays_d,
+                  int64_t n_rays, int n_samples, int white_bkgd, float* out_rgb, float* out_depth, float* out_weights, void* stream) {
+    if (n_rays < 0 || n_samples < 1) return fail(NRF_EINVAL, "bad sizes");
+    if (rgb_stride < 3 || sigma_stride < 1) return fail(NRF_EINVAL, "bad strides");
+    if (n_rays == 0) return NRF_OK;
+    if (!rgb || !sigma || !z_vals || !rays_d || !out_rgb) return fail(NRF_EINVAL, "null pointer");
+    const int r = nrf::launch_composite(rgb, rgb_stride, sigma, sigma_stride, z_vals, rays_d, n_rays, n_samples, white_bkgd, out_rgb,
+                                        out_depth, out_weights, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "composite launch failed");
+}
+
+int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance, const float* u,
+                   float* samples, float* z_union, void* stream) {
+    if (n_rays < 0 || n_samples < 2 || n_importance < 1) return fail(NRF_EINVAL, "bad sizes");
+    if (n_rays == 0) return NRF_OK;
+    if (!z_vals || !weights || (!samples && !z_union)) return fail(NRF_EINVAL, "null pointer");
+    const int r = nrf::launch_sample_pdf(z_vals, weights, n_rays, n_samples, n_importance, u, samples, z_union, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, r == NRF_EINVAL ? "n_samples + n_importance too large for one LDS row" : "sample_pdf launch failed");
+}
+
+int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int mma_mode, uint8_t* stream_out, int64_t stream_cap,
+                   int64_t* stream_bytes, float* bias_out, int64_t bias_cap, int64_t* n_bias) {
+    if (!arch || !linears || n_linear <= 0) return fail(NRF_EINVAL, "nrf_debug_pack: null argument");
+    if (mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "unknown mma_mode");
+    std::string err;
+    std::vector<nrf::HostLinear> lin;
+    nrf::NetPlan plan;
+    if (!copy_linears(linears, n_linear, lin, err) || !nrf::make_plan(*arch, lin, plan, err)) return fail(NRF_EINVAL, err);
+    const nrf::PackedStream ps = nrf::pack_stream(plan, lin, mma_mode);
+    const std::vector<float> b = nrf::pack_bias(plan, lin);
+    if (stream_bytes) *stream_bytes = (int64_t)ps.bytes.size();
+    if (n_bias) *n_bias = (int64_t)b.size();
+    if (stream_out) {
+        if (stream_cap < (int64_t)ps.bytes.size()) return fail(NRF_EINVAL, "stream_out too small");
+        std::memcpy(stream_out, ps.bytes.data(), ps.bytes.size());
+    }
+    if (bias_out) {
+        if (bias_cap < (int64_t)b.size()) return fail(NRF_EINVAL, "bias_out too small");
+        std::memcpy(bias_out, b.data(), b.size() * sizeof(float));
+    }
+    return NRF_OK;
+}
+
+int nrf_project_fetch(const nrf_dino* dino, const float* points, int64_t n, float* feats, float* xy, void* stream) {
+    if (n < 0) return fail(NRF_EINVAL, "n < 0");
+    if (n == 0) return NRF_OK;
+    if (!points || !feats) return fail(NRF_EINVAL, "null pointer");
+    nrf::DinoDev d{};
+    std::string err;
+    if (!make_dino(dino, 0, d, err)) return fail(NRF_EINVAL, err);
+    const int r = nrf::launch_project_fetch(d, points, n, feats, xy, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "project_fetch launch failed");
+}
+
+}  // extern "C"

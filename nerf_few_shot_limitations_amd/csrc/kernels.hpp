@@ -1,0 +1,73 @@
+// kernels.hpp -- host-visible launch interface between api.cpp and the .hip files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/nerfhip.h"
+#include "device_math.hpp"
+
+namespace nrf {
+
+// device-side image of one nrf_model
+struct DeviceNet {
+    nrf_arch arch;
+    const void* stream[3];      // packed fragment streams, indexed by NRF_MMA_*
+    uint32_t n_chunks[3];
+    const float* bias;          // bias table (fp32, shared by all modes)
+    int n_bias;
+    int64_t flops_per_sample;
+    int device;
+    int cu_count;
+};
+
+struct DinoDev {                // V3 side channel, by value in the kernel arguments
+    const float* features;
+    int Hp, Wp, C;
+    float inv_pose[12];         // first 3 rows of inverse(pose)
+    float focal;
+    int H, W;
+};
+
+struct RenderArgs {
+    // rays: explicit (rays_o/rays_d) or camera (cam + ray_begin)
+    const float* rays_o;
+    const float* rays_d;
+    int camera_mode;
+    Camera cam;
+    int64_t ray_begin;
+    int64_t n_rays;
+    // sampling
+    float near, far;
+    int n_samples, lindisp, perturb;
+    const float* t_rand;
+    uint64_t seed;
+    // compositing
+    float ert_eps;
+    int white_bkgd;
+    // outputs
+    float* rgb;
+    float* depth;
+    float* weights;
+    float* z_vals;
+    DinoDev dino;
+};
+
+int launch_render(const DeviceNet& net, int mma_mode, const RenderArgs& a, hipStream_t s, std::string& err);
+int launch_forward_v1(const DeviceNet& net, int mma_mode, const float* x_enc, int64_t n, float* out4, hipStream_t s, std::string& err);
+int launch_forward(const DeviceNet& net, int mma_mode, const float* pos, const float* dir, const float* dino, int64_t n,
+                   float* rgb, float* density, hipStream_t s, std::string& err);
+
+// staged kernels (staged_kernels.hip)
+int launch_get_rays(const Camera& cam, int64_t ray_begin, int64_t n, float* rays_o, float* rays_d, hipStream_t s);
+int launch_sample(const float* rays_o, const float* rays_d, int64_t n_rays, float near, float far, int S, int lindisp,
+                  int perturb, const float* t_rand, uint64_t seed, float* pts, float* z_vals, hipStream_t s);
+int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, float* out, hipStream_t s);
+int launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
+                     int64_t n_rays, int S, int white_bkgd, float* out_rgb, float* out_depth, float* out_w, hipStream_t s);
+int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, float* samples,
+                      float* z_union, hipStream_t s);
+int launch_project_fetch(const DinoDev& d, const float* points, int64_t n, float* feats, float* xy, hipStream_t s);
+
+}  // namespace nrf

@@ -1,0 +1,211 @@
+// packing.cpp -- host-side weight packer (see packing.hpp / mlp_core.hpp).
+#include "packing.hpp"
+
+#include <cmath>
+#include <cstring>
+
+#include "feature_map.hpp"
+
+namespace nrf {
+
+namespace {
+constexpr int kFragBytes = 1024, kChunkFrags = 16;
+
+uint32_t f32_bits(float x) { uint32_t u; std::memcpy(&u, &x, 4); return u; }
+}  // namespace
+
+uint16_t f32_to_bf16(float x) {                      // round to nearest even, NaN stays NaN
+    uint32_t u = f32_bits(x);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) return (uint16_t)((u >> 16) | 0x0040u);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+uint16_t f32_to_f16(float x) {                       // round to nearest even, subnormals kept, overflow -> inf
+    const uint32_t u = f32_bits(x);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t e = (u >> 23) & 0xFFu;
+    uint32_t m = u & 0x007FFFFFu;
+    if (e == 0xFFu) return (uint16_t)(sign | 0x7C00u | (m ? 0x0200u : 0u));
+    int32_t ne = (int32_t)e - 127 + 15;
+    if (ne >= 31) return (uint16_t)(sign | 0x7C00u);
+    if (ne <= 0) {
+        if (ne < -10) return (uint16_t)sign;
+        m |= 0x00800000u;
+        const int shift = 14 - ne;                   // 14..24
+        uint32_t hm = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (hm & 1u))) ++hm;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t h = ((uint32_t)ne << 10) | (m >> 13);
+    const uint32_t rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;   // may carry into the exponent: still correct
+    return (uint16_t)(sign | h);
+}
+
+int expected_linears(const nrf_arch& a) {
+    switch (a.net) {
+        case NRF_NET_V1: return a.n_layers + 2;
+        case NRF_NET_V2: return a.n_layers + 5;
+        case NRF_NET_V3: return a.n_layers + 10;
+        default: return 0;
+    }
+}
+
+namespace {
+
+std::vector<int> identity_cols(int n) {
+    std::vector<int> c(n);
+    for (int i = 0; i < n; ++i) c[i] = i;
+    return c;
+}
+
+// columns of a Linear fed by PE(L): kernel K index -> reference feature index (+ base)
+void pe_cols(std::vector<int>& col, int k0, int L, int base) {
+    const int KT = pe_tiles(L);
+    for (int k = 0; k < 32 * KT; ++k) {
+        const int idx = pe_ref_index(L, k_slot(k), k_half(k));
+        col[k0 + k] = idx < 0 ? -1 : base + idx;
+    }
+}
+
+std::vector<std::pair<int, int>> rows_of(int lin, int n_rows, int MT) {
+    std::vector<std::pair<int, int>> r(32 * MT, {-1, 0});
+    for (int i = 0; i < n_rows; ++i) r[i] = {lin, i};
+    return r;
+}
+
+bool check(const std::vector<HostLinear>& lin, int i, int out_f, int in_f, const char* name, std::string& err) {
+    if (lin[i].out_f != out_f || lin[i].in_f != in_f) {
+        err = std::string("linear '") + name + "' (index " + std::to_string(i) + ") has shape (" +
+              std::to_string(lin[i].out_f) + "," + std::to_string(lin[i].in_f) + "), expected (" +
+              std::to_string(out_f) + "," + std::to_string(in_f) + ")";
+        return false;
+    }
+    return true;
+}
+
+}  // namespace
+
+bool make_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, NetPlan& plan, std::string& err) {
+    plan = NetPlan();
+    if (a.hidden != 256) { err = "only hidden=256 is built (every experiments/*.yaml uses 256)"; return false; }
+    if (a.n_layers < 1 || a.n_layers > 16) { err = "n_layers must be in 1..16"; return false; }
+    if (a.pos_freq < 1 || a.pos_freq > 15) { err = "pos_freq must be in 1..15"; return false; }
+    if ((int)lin.size() != expected_linears(a)) {
+        err = "expected " + std::to_string(expected_linears(a)) + " Linear layers, got " + std::to_string(lin.size());
+        return false;
+    }
+    const int H = a.hidden, HT = H / 32;
+    const int pe = pe_dim(a.pos_freq), peT = pe_tiles(a.pos_freq);
+    auto add = [&](LayerPlan&& L) { plan.layers.push_back(std::move(L)); };
+
+    if (a.net == NRF_NET_V1) {
+        const int n = a.n_layers;
+        for (int i = 0; i < n; ++i)
+            if (!check(lin, i, H, i == 0 ? pe : H, "layers.N", err)) return false;
+        if (!check(lin, n, 1, H, "sigma_out", err) || !check(lin, n + 1, 3, H, "rgb_out", err)) return false;
+        LayerPlan L0; L0.KT = peT; L0.MT = HT; L0.col.assign(32 * peT, -1); pe_cols(L0.col, 0, a.pos_freq, 0);
+        L0.row = rows_of(0, H, HT); add(std::move(L0));
+        for (int i = 1; i < n; ++i) {
+            LayerPlan L; L.KT = HT; L.MT = HT; L.col = identity_cols(H); L.row = rows_of(i, H, HT); add(std::move(L));
+        }
+        // head tile: rows 0..2 = rgb_out, row 3 = sigma_out, rows 4..7 repeat them so that BOTH lane
+        // halves find [r,g,b,sigma] in accumulator registers 0..3
+        LayerPlan Hd; Hd.KT = HT; Hd.MT = 1; Hd.col = identity_cols(H); Hd.row.assign(32, {-1, 0});
+        for (int rep = 0; rep < 2; ++rep) {
+            for (int c = 0; c < 3; ++c) Hd.row[4 * rep + c] = {n + 1, c};
+            Hd.row[4 * rep + 3] = {n, 0};
+        }
+        add(std::move(Hd));
+    } else if (a.net == NRF_NET_V2) {
+        if (a.dir_freq < 1 || 3 * a.dir_freq + 2 > 16) { err = "dir_freq must be in 1..4 (one operand tile)"; return false; }
+        const int n = a.n_layers, de = pe_dim(a.dir_freq);
+        for (int i = 0; i < n; ++i)
+            if (!check(lin, i, H, i == 0 ? pe : H, "density_layers.N", err)) return false;
+        if (!check(lin, n, 1, H, "density_head", err) || !check(lin, n + 1, H, H, "feature_head", err) ||
+            !check(lin, n + 2, H / 2, H + de, "color_layers.0", err) || !check(lin, n + 3, H / 4, H / 2, "color_layers.2", err) ||
+            !check(lin, n + 4, 3, H / 4, "color_layers.4", err))
+            return false;
+        LayerPlan L0; L0.KT = peT; L0.MT = HT; L0.col.assign(32 * peT, -1); pe_cols(L0.col, 0, a.pos_freq, 0);
+        L0.row = rows_of(0, H, HT); add(std::move(L0));
+        for (int i = 1; i < n; ++i) {
+            LayerPlan L; L.KT = HT; L.MT = HT; L.col = identity_cols(H); L.row = rows_of(i, H, HT); add(std::move(L));
+        }
+        LayerPlan Dh; Dh.KT = HT; Dh.MT = 1; Dh.col = identity_cols(H); Dh.row.assign(32, {-1, 0});
+        Dh.row[0] = {n, 0}; Dh.row[4] = {n, 0}; add(std::move(Dh));                    // density in reg 0 of both halves
+        LayerPlan Fh; Fh.KT = HT; Fh.MT = HT; Fh.col = identity_cols(H); Fh.row = rows_of(n + 1, H, HT); add(std::move(Fh));
+        LayerPlan C0; C0.KT = HT + 1; C0.MT = H / 64; C0.col.assign(32 * (HT + 1), -1);
+        for (int k = 0; k < H; ++k) C0.col[k] = k;
+        pe_cols(C0.col, H, a.dir_freq, H);
+        C0.row = rows_of(n + 2, H / 2, H / 64); add(std::move(C0));
+        LayerPlan C2; C2.KT = H / 64; C2.MT = H / 128; C2.col = identity_cols(H / 2); C2.row = rows_of(n + 3, H / 4, H / 128); add(std::move(C2));
+        LayerPlan C4; C4.KT = H / 128; C4.MT = 1; C4.col = identity_cols(H / 4); C4.row.assign(32, {-1, 0});
+        for (int rep = 0; rep < 2; ++rep)
+            for (int c = 0; c < 3; ++c) C4.row[4 * rep + c] = {n + 4, c};
+        add(std::move(C4));
+    } else {
+        err = "network family not built into this library yet";
+        return false;
+    }
+
+    int off = 0;
+    for (auto& L : plan.layers) { L.bias_off = off; off += 32 * L.MT; }
+    plan.n_bias = off;
+    int64_t mac = 0;
+    for (const auto& l : lin) mac += (int64_t)l.out_f * l.in_f;
+    plan.flops_per_sample = 2 * mac;
+    return true;
+}
+
+std::vector<float> pack_bias(const NetPlan& plan, const std::vector<HostLinear>& lin) {
+    std::vector<float> b(plan.n_bias, 0.0f);
+    for (const auto& L : plan.layers)
+        for (int r = 0; r < 32 * L.MT; ++r)
+            if (L.row[r].first >= 0) b[L.bias_off + r] = lin[L.row[r].first].b[L.row[r].second];
+    return b;
+}
+
+PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin, int mode) {
+    const bool f32 = (mode == NRF_MMA_F32);
+    const int SUB = f32 ? 4 : 2;
+    PackedStream out;
+    size_t total_frags = 0;
+    for (const auto& L : plan.layers) {
+        const size_t f = (size_t)L.MT * L.KT * SUB;
+        total_frags += (f + kChunkFrags - 1) / kChunkFrags * kChunkFrags;
+    }
+    out.bytes.assign(total_frags * kFragBytes, 0);
+    out.n_chunks = (uint32_t)(total_frags / kChunkFrags);
+    size_t frag = 0;
+    for (const auto& L : plan.layers) {
+        for (int m = 0; m < L.MT; ++m)
+            for (int t = 0; t < L.KT; ++t)
+                for (int s = 0; s < SUB; ++s, ++frag) {
+                    uint8_t* dst = out.bytes.data() + frag * kFragBytes;
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int i = lane & 31, h = lane >> 5;
+                        const auto& rs = L.row[32 * m + i];
+                        const int n_el = f32 ? 4 : 8;
+                        for (int e = 0; e < n_el; ++e) {
+                            const int k = f32 ? (32 * t + 8 * s + 4 * h + e)
+                                              : (32 * t + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3));
+                            float v = 0.0f;
+                            if (rs.first >= 0 && L.col[k] >= 0)
+                                v = lin[rs.first].w[(size_t)rs.second * lin[rs.first].in_f + L.col[k]];
+                            if (f32) {
+                                std::memcpy(dst + lane * 16 + e * 4, &v, 4);
+                            } else {
+                                const uint16_t q = (mode == NRF_MMA_BF16) ? f32_to_bf16(v) : f32_to_f16(v);
+                                std::memcpy(dst + lane * 16 + e * 2, &q, 2);
+                            }
+                        }
+                    }
+                }
+        frag = (frag + kChunkFrags - 1) / kChunkFrags * kChunkFrags;   // every layer starts on a chunk boundary
+    }
+    return out;
+}
+
+}  // namespace nrf

@@ -13,6 +13,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the native library is the product under test: (re)build it if it is missing or stale
+    from nerf_few_shot_limitations_amd import build as _b
+    _b.build()
 
 
 def load_golden(name):

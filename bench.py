@@ -5,7 +5,7 @@
 
 Workload (BASELINE.json metric): synthetic 800x800 camera frames, 64 samples per ray, the 8x256
 NeRF MLP (nerf_model.NeRFMLP, 951 808 FLOP per ray-sample), deterministic random-init weights
-("fog" scene: no ray saturates; early ray termination OFF), bf16 MFMA.  One step renders
+("solid" scene; early ray termination OFF, so every one of the R*S samples is evaluated), bf16 MFMA.  One step renders
 n_gpus frames: every frame's rays are sharded by contiguous pixel band over the ranks (rank r
 renders rays [r*HW/N, (r+1)*HW/N) of every frame -> per-GPU work is one frame's worth of rays,
 weak scaling) and the finished bands are exchanged with ONE RCCL all_gather per step so that
@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--net", default="v1", choices=["v1", "v2"])
-    ap.add_argument("--scene", default="fog", choices=["fog", "solid"])
+    ap.add_argument("--scene", default="solid", choices=["fog", "solid"])
     ap.add_argument("--ert", type=float, default=0.0)
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
     args = ap.parse_args()
@@ -110,6 +110,7 @@ def main():
     for _ in range(args.warmup):
         step(False)
     sync()
+    print(f"[bench] rank {rank}: warmup done", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -142,7 +143,9 @@ def main():
 
     if rank == 0 and world == 1 and args.cpu_rows > 0:
         # CPU oracle on a band of rows of the same frame (port of the reference's torch-CPU path)
-        threads = os.cpu_count() or 1
+        # the box's CPU share, not the host's core count (a cgroup-limited box reports far more cores than it may use)
+        threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("NERF_BENCH_CPU_THREADS", "16")))
+        print(f"[bench] GPU part done: {value:.1f} M samples/s; timing the CPU oracle on {threads} threads ...", file=sys.stderr, flush=True)
         torch.set_num_threads(threads)
         rows = min(args.cpu_rows, H)
         r0 = (H // 2) * W
@@ -156,6 +159,7 @@ def main():
             ref = O.render_rays(p, args.net, ro, rd, 2.0, 6.0, S, chunk=2048)
             el = time.perf_counter() - tc
             best = el if best is None else min(best, el)
+            print(f"[bench] cpu oracle pass: {el:.2f} s", file=sys.stderr, flush=True)
         out["cpu_baseline"] = {"value": round(rows * W * S / best / 1e6, 4), "unit": "M ray-samples/s", "cores": threads,
                                "kind": "port", "sample": f"{rows} rows ({rows * W} rays x {S} samples) of the same {H}x{W} frame, "
                                                           f"torch fp32 CPU, chunk 2048 rays, best of 3"}

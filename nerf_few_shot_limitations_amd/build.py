@@ -22,7 +22,7 @@ INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
 SOURCES = ["fused_kernels.hip", "staged_kernels.hip", "api.cpp", "packing.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function",
-         "-fno-gpu-rdc", f"-I{INCLUDE}"]
+         "-fno-gpu-rdc", "-ffp-contract=off", f"-I{INCLUDE}"]
 
 
 def hipcc() -> str:

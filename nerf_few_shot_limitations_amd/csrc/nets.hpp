@@ -42,7 +42,7 @@ __device__ __forceinline__ void encode3(const float p[3], int h, typename Mode::
             constexpr float scale = (float)(1u << f);
             if constexpr (Mode::FAST_TRIG) {
                 // turns: fract() of the exact scaled high part + scaled low part; cos = sin a quarter turn on
-                const float rev = __builtin_amdgcn_fractf(hi[c] * scale) + lo[c] * scale + quarter;
+                const float rev = __builtin_fmaf(lo[c], scale, __builtin_amdgcn_fractf(hi[c] * scale)) + quarter;
                 v = __builtin_amdgcn_sinf(rev);
             } else {
                 v = precise_sin_or_cos(p[c] * scale, h);

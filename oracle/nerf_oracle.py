@@ -440,21 +440,34 @@ def layer_shapes(variant: str, pos_freq=None, dir_freq=4, hidden=256, n_layers=8
 
 
 def make_weights(variant: str, seed: int = 0, scene: str = "fog", **kw) -> Dict[str, torch.Tensor]:
-    """Deterministic nn.Linear-default-range weights for a variant.
+    """Deterministic weights for a variant: nn.Linear default-init ranges for every layer, then
+    rescaled so that the synthetic scene is not degenerate (raw default init shrinks the signal by
+    ~sqrt(6) per layer: after 8 layers the outputs are constants, sigma <= 0 almost everywhere, a
+    black frame):
 
-    scene 'fog'  : raw init (sigma small everywhere; no ray saturates) -- the ERT-off roofline case.
-    scene 'solid': density head weight x40 and bias +1.5, so a sizeable share of
-                   rays saturate early -- the early-ray-termination case.
+    both scenes: every hidden Linear weight x sqrt(6) (variance-preserving for U(-1/sqrt(n),1/sqrt(n))
+                 weights behind a ReLU), so the radiance field really varies with position at all
+                 encoding frequencies; colour head weight x6 (colours spread over (0,1) instead of hugging 0.5);
+    scene 'fog'  : density head bias +0.25 -> thin participating medium, no ray saturates
+                   (the ERT-off roofline case);
+    scene 'solid': density head weight x40 and bias +1.5 -> a sizeable share of rays saturate
+                   early (the early-ray-termination case).
     """
     p = {}
     for i, (name, o, n_in) in enumerate(layer_shapes(variant, **kw)):
         w, b = _linear_init(seed * 1000 + i, o, n_in)
+        if o >= 32:
+            w = w * math.sqrt(6.0)
         p[name + ".weight"], p[name + ".bias"] = w, b
+    dens = "sigma_out" if variant == "v1" else "density_mlp.density_head"
+    col = "rgb_out" if variant == "v1" else "color_mlp.color_layers.4"
+    p[col + ".weight"] = p[col + ".weight"] * 6.0
     if scene == "solid":
-        head = "sigma_out" if variant == "v1" else "density_mlp.density_head"
-        p[head + ".weight"] = p[head + ".weight"] * 40.0
-        p[head + ".bias"] = p[head + ".bias"] + 1.5
-    elif scene != "fog":
+        p[dens + ".weight"] = p[dens + ".weight"] * 40.0
+        p[dens + ".bias"] = p[dens + ".bias"] + 1.5
+    elif scene == "fog":
+        p[dens + ".bias"] = p[dens + ".bias"] + 0.25
+    else:
         raise ValueError(scene)
     return p
 

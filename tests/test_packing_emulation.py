@@ -95,7 +95,8 @@ def test_v1_stream_replay_matches_oracle(L, mode, tol):
     ref = O.mlp_v1(p, O.positional_encoding(torch.from_numpy(x), 10)).numpy()
     ref_raw = ref.copy()
     ref_raw[:, :3] = np.log(ref[:, :3] / (1 - ref[:, :3]))                # undo the sigmoid: the head tile holds logits
-    assert np.abs(got - ref_raw).max() < tol, np.abs(got - ref_raw).max()
+    scale = max(1.0, float(np.abs(ref_raw).max()))
+    assert np.abs(got - ref_raw).max() < tol * scale, (np.abs(got - ref_raw).max(), scale)
     assert np.array_equal(got, got_hi)
 
 
@@ -124,7 +125,7 @@ def test_v2_stream_replay_matches_oracle(L, mode, tol):
     ref_rgb, ref_dens = O.mlp_v2(p, torch.from_numpy(x), torch.from_numpy(d))
     got_rgb = 1 / (1 + np.exp(-np.stack([rgb[0, :32, k] for k in range(3)], -1)))
     assert np.abs(got_rgb - ref_rgb.numpy()).max() < tol
-    assert np.abs(np.maximum(dens[0, :32, 0], 0) - ref_dens.numpy()[:, 0]).max() < tol
+    assert np.abs(np.maximum(dens[0, :32, 0], 0) - ref_dens.numpy()[:, 0]).max() < tol * max(1.0, float(ref_dens.max()))
     assert np.array_equal(dens[0, :32, 0], dens[0, 32:, 0])               # both lane halves see the density
 
 

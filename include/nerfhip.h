@@ -88,6 +88,10 @@ typedef struct nrf_render_opts {
     int32_t  lindisp;        /* ray_utils.py:59-62                                                    */
     int32_t  perturb;        /* 1: stratified jitter (ray_utils.py:71-79)                             */
     const float* t_rand;     /* device (R,S) U[0,1) jitter, or NULL -> in-kernel counter RNG(rng_seed) */
+    const float* z_ladder;   /* device (S) un-jittered depths z_0..z_{S-1}, or NULL -> computed in-kernel from near/far
+                                (scalar torch.linspace formula).  torch's CPU linspace is vectorised and its last ulp
+                                depends on the host: a caller that must match the reference bit for bit passes the
+                                ladder the reference computes (ray_utils.py:58-66) */
     uint64_t rng_seed;
     float    ert_eps;        /* early ray termination: stop a wave once every live ray has T < eps; 0 = off (reference behaviour) */
     int32_t  white_bkgd;     /* nerf_mlp.py:209-212                                                   */
@@ -136,7 +140,7 @@ int nrf_get_rays(int H, int W, float focal, const float c2w[12], int64_t ray_beg
 /* ray_utils.py:39-84 == ray_sampler.py:32-61.  pts (R,S,3) and/or z_vals (R,S) (either may be NULL). */
 int nrf_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays,
                           float near, float far, int n_samples, int lindisp, int perturb,
-                          const float* t_rand, uint64_t rng_seed,
+                          const float* t_rand, const float* z_ladder, uint64_t rng_seed,
                           float* pts, float* z_vals, void* stream);
 /* positional_encoding.py:20-33 == nerf_mlp.py:17-33.  x (n,dim) -> out (n, dim*(2L+include_input)). */
 int nrf_encode(const float* x, int64_t n, int dim, int num_freqs, int include_input, float* out, void* stream);

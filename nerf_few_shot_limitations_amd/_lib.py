@@ -43,7 +43,7 @@ class nrf_dino(C.Structure):
 
 class nrf_render_opts(C.Structure):
     _fields_ = [("near", C.c_float), ("far", C.c_float), ("n_samples", C.c_int32), ("lindisp", C.c_int32),
-                ("perturb", C.c_int32), ("t_rand", C.c_void_p), ("rng_seed", C.c_uint64), ("ert_eps", C.c_float),
+                ("perturb", C.c_int32), ("t_rand", C.c_void_p), ("z_ladder", C.c_void_p), ("rng_seed", C.c_uint64), ("ert_eps", C.c_float),
                 ("white_bkgd", C.c_int32), ("mma_mode", C.c_int32), ("dino", C.POINTER(nrf_dino))]
 
 
@@ -61,7 +61,7 @@ SIGNATURES = {
                                     C.POINTER(nrf_render_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_get_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float * 12, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_sample_along_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
-                                        C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "nrf_mlp_forward_v1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nrf_mlp_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -126,3 +126,21 @@ def stream_ptr():
 def require_gpu():
     if not torch.cuda.is_available():
         raise RuntimeError("nerf_few_shot_limitations_amd needs an MI355X (gfx950) GPU: no HIP device is visible and there is no CPU path")
+
+
+_ladders = {}
+
+
+def z_ladder(near, far, n_samples, lindisp, device):
+    """The un-jittered depth ladder exactly as the reference computes it on THIS host
+    (src/utils/ray_utils.py:58-66: torch.linspace on the CPU, then near*(1-t)+far*t), on `device`."""
+    key = (float(near), float(far), int(n_samples), bool(lindisp), str(device))
+    z = _ladders.get(key)
+    if z is None:
+        t = torch.linspace(0., 1., int(n_samples))
+        z = 1. / (1. / near * (1. - t) + 1. / far * t) if lindisp else near * (1. - t) + far * t
+        z = z.to(dtype=torch.float32).to(device).contiguous()
+        if len(_ladders) > 64:
+            _ladders.clear()
+        _ladders[key] = z
+    return z

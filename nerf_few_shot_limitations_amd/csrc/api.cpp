@@ -127,7 +127,7 @@ int check_opts(const nrf_render_opts* o) {
 
 void fill_common(nrf::RenderArgs& a, const nrf_render_opts* o, float* rgb, float* depth, float* weights, float* z_vals) {
     a.near = o->near; a.far = o->far; a.n_samples = o->n_samples; a.lindisp = o->lindisp; a.perturb = o->perturb;
-    a.t_rand = o->perturb ? o->t_rand : nullptr; a.seed = o->rng_seed;
+    a.t_rand = o->perturb ? o->t_rand : nullptr; a.z_ladder = o->z_ladder; a.seed = o->rng_seed;
     a.ert_eps = o->ert_eps; a.white_bkgd = o->white_bkgd;
     a.rgb = rgb; a.depth = depth; a.weights = weights; a.z_vals = z_vals;
 }
@@ -243,11 +243,12 @@ int nrf_get_rays(int H, int W, float focal, const float c2w[12], int64_t ray_beg
 }
 
 int nrf_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_rays, float near, float far, int n_samples, int lindisp,
-                          int perturb, const float* t_rand, uint64_t rng_seed, float* pts, float* z_vals, void* stream) {
+                          int perturb, const float* t_rand, const float* z_ladder, uint64_t rng_seed, float* pts, float* z_vals,
+                          void* stream) {
     if (n_rays < 0 || n_samples < 1) return fail(NRF_EINVAL, "bad sizes");
     if (n_rays == 0) return NRF_OK;
     if (!rays_o || !rays_d || (!pts && !z_vals)) return fail(NRF_EINVAL, "null pointer");
-    const int r = nrf::launch_sample(rays_o, rays_d, n_rays, near, far, n_samples, lindisp, perturb, perturb ? t_rand : nullptr, rng_seed,
+    const int r = nrf::launch_sample(rays_o, rays_d, n_rays, near, far, n_samples, lindisp, perturb, perturb ? t_rand : nullptr, z_ladder, rng_seed,
                                      pts, z_vals, (hipStream_t)stream);
     return r == NRF_OK ? NRF_OK : fail(r, "sample launch failed");
 }

@@ -39,12 +39,14 @@ __device__ __forceinline__ void camera_ray(const Camera& c, int64_t ray, float o
 struct DepthLadder {      // ray_utils.py:58-66
     float near, far, step;   // step = 1/(S-1) of linspace(0,1,S)
     int   S, lindisp;
+    const float* table;      // optional caller-computed ladder z_0..z_{S-1} (device); see ladder_z
 };
 
-__device__ __forceinline__ DepthLadder make_ladder(float near, float far, int S, int lindisp) {
+__host__ __device__ __forceinline__ DepthLadder make_ladder(float near, float far, int S, int lindisp, const float* table) {
     DepthLadder L;
     L.near = near; L.far = far; L.S = S; L.lindisp = lindisp;
     L.step = S > 1 ? 1.0f / (float)(S - 1) : 0.0f;
+    L.table = table;
     return L;
 }
 
@@ -57,7 +59,11 @@ __device__ __forceinline__ float ladder_t(const DepthLadder& L, int s) {
 }
 
 // un-jittered depth of sample s: near*(1-t) + far*t, or its disparity form (ray_utils.py:62,66)
+// A caller-supplied table wins: torch.linspace's CPU kernel is vectorised and its last-ulp results
+// depend on the host's SIMD width, and the encoding amplifies a 1-ulp depth difference by 2^(L-1), so
+// the drop-in Python surface hands over the very ladder the reference would compute on that host.
 __device__ __forceinline__ float ladder_z(const DepthLadder& L, int s) {
+    if (L.table) return L.table[s];
     const float t = ladder_t(L, s);
     if (L.lindisp) {
         const float a = __fmul_rn(1.0f / L.near, __fsub_rn(1.0f, t));

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(kThreads) render_kernel(const RenderKArgs P) {
 
     const RenderArgs& a = P.a;
     const int S = a.n_samples;
-    const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp);
+    const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, a.z_ladder);
     const int own = (NT == 2) ? h : 0;
     const bool owner = h < NT;
 

@@ -42,6 +42,7 @@ struct RenderArgs {
     float near, far;
     int n_samples, lindisp, perturb;
     const float* t_rand;
+    const float* z_ladder;
     uint64_t seed;
     // compositing
     float ert_eps;
@@ -62,7 +63,7 @@ int launch_forward(const DeviceNet& net, int mma_mode, const float* pos, const f
 // staged kernels (staged_kernels.hip)
 int launch_get_rays(const Camera& cam, int64_t ray_begin, int64_t n, float* rays_o, float* rays_d, hipStream_t s);
 int launch_sample(const float* rays_o, const float* rays_d, int64_t n_rays, float near, float far, int S, int lindisp,
-                  int perturb, const float* t_rand, uint64_t seed, float* pts, float* z_vals, hipStream_t s);
+                  int perturb, const float* t_rand, const float* z_ladder, uint64_t seed, float* pts, float* z_vals, hipStream_t s);
 int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, float* out, hipStream_t s);
 int launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
                      int64_t n_rays, int S, int white_bkgd, float* out_rgb, float* out_depth, float* out_w, hipStream_t s);

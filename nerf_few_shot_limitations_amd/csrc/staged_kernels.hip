@@ -220,9 +220,9 @@ int launch_get_rays(const Camera& cam, int64_t ray_begin, int64_t n, float* rays
 }
 
 int launch_sample(const float* rays_o, const float* rays_d, int64_t n_rays, float near, float far, int S, int lindisp, int perturb,
-                  const float* t_rand, uint64_t seed, float* pts, float* z_vals, hipStream_t s) {
+                  const float* t_rand, const float* z_ladder, uint64_t seed, float* pts, float* z_vals, hipStream_t s) {
     if (n_rays <= 0) return NRF_OK;
-    const DepthLadder lad = {near, far, S > 1 ? 1.0f / (float)(S - 1) : 0.0f, S, lindisp};
+    const DepthLadder lad = make_ladder(near, far, S, lindisp, z_ladder);
     hipLaunchKernelGGL(sample_kernel, dim3(grid_for(n_rays * S, kBlock, 8192)), dim3(kBlock), 0, s, rays_o, rays_d, n_rays, lad, perturb,
                        t_rand, seed, pts, z_vals);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;

@@ -53,8 +53,10 @@ def sample_points_along_rays(rays_o, rays_d, near, far, N_samples, perturb=True,
     with torch.cuda.device(o.device):
         pts = torch.empty((R, S, 3), dtype=torch.float32, device=o.device)
         z = torch.empty((R, S), dtype=torch.float32, device=o.device)
+        lad = L.z_ladder(near, far, S, lindisp, o.device)
         L.check(L.lib().nrf_sample_along_rays(L.ptr(o2), L.ptr(d2), R, float(near), float(far), S, int(bool(lindisp)),
-                                              int(bool(perturb) or tr is not None), L.ptr(tr), int(seed), L.ptr(pts), L.ptr(z), L.stream_ptr()))
+                                              int(bool(perturb) or tr is not None), L.ptr(tr), L.ptr(lad), int(seed), L.ptr(pts), L.ptr(z),
+                                              L.stream_ptr()))
     return pts.reshape(*lead, S, 3), z.reshape(*lead, S)
 
 

@@ -34,11 +34,12 @@ def make_dino(features, pose, focal, H, W):
     return d, fm
 
 
-def _opts(near, far, n_samples, perturb, t_rand, seed, lindisp, ert_eps, white_bkgd, mma_mode, dino):
+def _opts(near, far, n_samples, perturb, t_rand, seed, lindisp, ert_eps, white_bkgd, mma_mode, dino, device):
     o = L.nrf_render_opts()
     o.near, o.far, o.n_samples, o.lindisp = float(near), float(far), int(n_samples), int(bool(lindisp))
     o.perturb = int(bool(perturb) or t_rand is not None)
     o.t_rand = t_rand.data_ptr() if t_rand is not None else None
+    o.z_ladder = L.z_ladder(near, far, n_samples, lindisp, device).data_ptr()     # cached per (near, far, S, device)
     o.rng_seed = int(seed)
     o.ert_eps, o.white_bkgd, o.mma_mode = float(ert_eps), int(bool(white_bkgd)), L.MMA_MODES[mma_mode]
     o.dino = C.pointer(dino) if dino is not None else None
@@ -59,7 +60,7 @@ def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb
         if dino is None:
             raise ValueError("a use_dino model needs dino=dict(features=, pose=, focal=, H=, W=)")
         dn, keep = make_dino(**dino)
-    opts = _opts(near, far, S, perturb, tr, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn)
+    opts = _opts(near, far, S, perturb, tr, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn, o.device)
     h = model.handle(o.device)
     with torch.cuda.device(o.device):
         rgb = torch.empty((R, 3), dtype=torch.float32, device=o.device)
@@ -95,7 +96,7 @@ def render_camera(model: NeRFMLP, H, W, focal, c2w, near, far, N_samples=64, ray
         if dino is None:
             raise ValueError("a use_dino model needs dino=...")
         dn, keep = make_dino(**dino)
-    opts = _opts(near, far, N_samples, perturb, None, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn)
+    opts = _opts(near, far, N_samples, perturb, None, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn, device)
     h = model.handle(device)
     with torch.cuda.device(device):
         rgb = out_rgb if out_rgb is not None else torch.empty((n, 3), dtype=torch.float32, device=device)

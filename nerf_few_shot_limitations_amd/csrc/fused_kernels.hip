@@ -7,6 +7,8 @@
 // transmittance / colour / depth accumulators live in the registers of the lane that owns it
 // (lane (c,h) owns ray 32h+c of the wave) and a whole workgroup stops marching a tile as soon as
 // every one of its rays has T < ert_eps.
+#include <cstdlib>
+
 #include "kernels.hpp"
 #include "nets.hpp"
 
@@ -46,28 +48,28 @@ template <bool FAST>
 __device__ __forceinline__ float sigmoid_sel(float x) { return FAST ? sigmoid_fast(x) : sigmoid_precise(x); }
 
 __device__ __forceinline__ void load_bias_table(NRF_LDS float* bias, const float* src, int n) {
-    for (int i = threadIdx.x; i < n; i += kThreads) bias[i] = src[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) bias[i] = src[i];
     __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------
 // fused renderer
 // ---------------------------------------------------------------------------------------------
-template <class Net, class Mode, int NT, int LP, int LD>
-__global__ void __launch_bounds__(kThreads) render_kernel(const RenderKArgs P) {
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
+__global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NRF_LDS char* lds = (NRF_LDS char*)smem;
     NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
     NRF_LDS int* flags = (NRF_LDS int*)(bias + kBiasMaxFloats);
     typedef typename Mode::Act Act;
     constexpr int KT0 = pe_tiles(LP);
-    constexpr int TILE = kWaves * 32 * NT;
+    constexpr int TILE = WAVES * 32 * NT;
 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
 
-    Pipe pipe;
+    Pipe<WAVES> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds);
     pipe.start();
 
@@ -160,11 +162,14 @@ __global__ void __launch_bounds__(kThreads) render_kernel(const RenderKArgs P) {
             if (a.ert_eps > 0.0f && !last) {
                 // workgroup-level early termination: every ray of the tile is opaque
                 const int wave_dead = __all((!own_valid) || (comp.T < a.ert_eps));
-                if (lane == 0) flags[(s & 1) * kWaves + wave] = wave_dead;
+                if (lane == 0) flags[(s & 1) * WAVES + wave] = wave_dead;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                const NRF_LDS int* fl = flags + (s & 1) * kWaves;
-                if (fl[0] & fl[1] & fl[2] & fl[3]) { ++s; break; }
+                const NRF_LDS int* fl = flags + (s & 1) * WAVES;
+                int all_dead = 1;
+#pragma unroll
+                for (int wv = 0; wv < WAVES; ++wv) all_dead &= fl[wv];
+                if (all_dead) { ++s; break; }
             }
         }
         if (own_valid) {
@@ -190,20 +195,20 @@ __global__ void __launch_bounds__(kThreads) render_kernel(const RenderKArgs P) {
 // ---------------------------------------------------------------------------------------------
 // staged MLP forward on explicit per-sample inputs (NeRFMLP.forward drop-in)
 // ---------------------------------------------------------------------------------------------
-template <class Net, class Mode, int NT, int LP, int LD>
-__global__ void __launch_bounds__(kThreads) forward_kernel(const ForwardKArgs P) {
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
+__global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NRF_LDS char* lds = (NRF_LDS char*)smem;
     NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
     typedef typename Mode::Act Act;
     constexpr int KT0 = pe_tiles(LP);
-    constexpr int TILE = kWaves * 32 * NT;
+    constexpr int TILE = WAVES * 32 * NT;
     constexpr int PE = pe_dim(LP);
 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
-    Pipe pipe;
+    Pipe<WAVES> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds);
     pipe.start();
     const int own = (NT == 2) ? h : 0;
@@ -281,33 +286,33 @@ NetArgs net_args(const DeviceNet& net, int mode) {
     return n;
 }
 
-template <class Net, class Mode, int NT, int LP, int LD>
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
-    auto kernel = render_kernel<Net, Mode, NT, LP, LD>;
+    auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD>;
     static int prepared = prepare(kernel, err);
     if (prepared != NRF_OK) return prepared;
     RenderKArgs k;
     k.net = net_args(net, mode);
     k.a = a;
-    constexpr int TILE = kWaves * 32 * NT;
+    constexpr int TILE = WAVES * 32 * NT;
     k.n_tiles = (a.n_rays + TILE - 1) / TILE;
     const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, s, k);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("render launch: ") + hipGetErrorString(e); return NRF_EHIP; }
     return NRF_OK;
 }
 
-template <class Net, class Mode, int NT, int LP, int LD>
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_forward(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) {
-    auto kernel = forward_kernel<Net, Mode, NT, LP, LD>;
+    auto kernel = forward_kernel<Net, Mode, NT, WAVES, LP, LD>;
     static int prepared = prepare(kernel, err);
     if (prepared != NRF_OK) return prepared;
     k.net = net_args(net, mode);
-    constexpr int TILE = kWaves * 32 * NT;
+    constexpr int TILE = WAVES * 32 * NT;
     k.n_tiles = (k.n + TILE - 1) / TILE;
     const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kThreads), kLdsBytes, s, k);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("forward launch: ") + hipGetErrorString(e); return NRF_EHIP; }
     return NRF_OK;
@@ -322,11 +327,23 @@ bool check_net(const DeviceNet& net, int mode, std::string& err) {
 
 }  // namespace
 
-#define NRF_DISPATCH_MODE(FN, NET, LP, ...)                                                              \
-    switch (mode) {                                                                                      \
-        case NRF_MMA_BF16: return FN<NET<ModeBF16, 2, LP>, ModeBF16, 2, LP, 4>(__VA_ARGS__);             \
-        case NRF_MMA_F16:  return FN<NET<ModeF16, 2, LP>, ModeF16, 2, LP, 4>(__VA_ARGS__);               \
-        default:           return FN<NET<ModeF32, 1, LP>, ModeF32, 1, LP, 4>(__VA_ARGS__);               \
+// Workgroup geometry per arithmetic mode: 16-bit modes run 8 waves x 32 samples (two waves per SIMD, <= 256
+// registers, each covering the other's epilogue / waits); NRF_GEOMETRY=4x2 selects 4 waves x 64 samples.
+// The fp32 mode keeps 4 waves x 32 samples (its fp32 activations need > 256 registers).
+static bool wide_waves() {
+    static const bool w = [] { const char* e = getenv("NRF_GEOMETRY"); return !(e && std::string(e) == "4x2"); }();
+    return w;
+}
+
+#define NRF_DISPATCH_MODE(FN, NET, LP, ...)                                                                 \
+    switch (mode) {                                                                                         \
+        case NRF_MMA_BF16:                                                                                  \
+            if (wide_waves()) return FN<NET<ModeBF16, 1, LP>, ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);         \
+            return FN<NET<ModeBF16, 2, LP>, ModeBF16, 2, 4, LP, 4>(__VA_ARGS__);                            \
+        case NRF_MMA_F16:                                                                                   \
+            if (wide_waves()) return FN<NET<ModeF16, 1, LP>, ModeF16, 1, 8, LP, 4>(__VA_ARGS__);           \
+            return FN<NET<ModeF16, 2, LP>, ModeF16, 2, 4, LP, 4>(__VA_ARGS__);                              \
+        default: return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                         \
     }
 
 int launch_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {

@@ -38,9 +38,6 @@ constexpr int kFragBytes = 1024;                     // 64 lanes x 16 B
 constexpr int kChunkFrags = 16;
 constexpr int kChunkBytes = kFragBytes * kChunkFrags;  // 16 KiB
 constexpr int kSlots = 8;                              // ring depth (128 KiB)
-constexpr int kWaves = 4;                              // waves per workgroup
-constexpr int kThreads = kWaves * 64;
-constexpr int kFragsPerWave = kChunkFrags / kWaves;    // glds instructions per wave per chunk
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -54,7 +51,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---------------------------------------------------------------------------
 // weight streamer
 // ---------------------------------------------------------------------------
+// WAVES = waves of the workgroup that share the stream (4: one per SIMD, or 8: two per SIMD)
+template <int WAVES>
 struct Pipe {
+    static constexpr int kFragsPerWave = kChunkFrags / WAVES;    // glds instructions per wave per chunk
     const NRF_GLB char* src;   // packed stream + wave*4 KiB + lane*16
     NRF_LDS char* ring;        // ring base (LDS)
     NRF_LDS char* cur;         // current chunk + lane*16
@@ -186,8 +186,8 @@ __device__ __forceinline__ void load_bias(f32x16& acc, const NRF_LDS float* bias
 // tiles, KT input tiles, NT sample tiles.  Consumes MT*KT*SUB fragments from the pipe (the host
 // pads every layer to whole chunks, so a layer always starts on a chunk boundary).
 // `fin(m, acc)` receives each finished tile's raw accumulators.
-template <class Mode, int KT, int MT, int NT, class Fin>
-__device__ __forceinline__ void dense(Pipe& pipe, const NRF_LDS float* bias, int h,
+template <class Mode, int KT, int MT, int NT, class P, class Fin>
+__device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,
                                       const typename Mode::Act (&in)[KT][NT], Fin&& fin) {
     static_for<MT>([&](auto m_) {
         constexpr int m = decltype(m_)::value;
@@ -212,8 +212,8 @@ __device__ __forceinline__ void dense(Pipe& pipe, const NRF_LDS float* bias, int
 }
 
 // layer with an activation, producing the next layer's operand tiles
-template <class Mode, int KT, int MT, int NT, bool RELU>
-__device__ __forceinline__ void dense_act(Pipe& pipe, const NRF_LDS float* bias, int h,
+template <class Mode, int KT, int MT, int NT, bool RELU, class P>
+__device__ __forceinline__ void dense_act(P& pipe, const NRF_LDS float* bias, int h,
                                           const typename Mode::Act (&in)[KT][NT], typename Mode::Act (&out)[MT][NT]) {
     dense<Mode, KT, MT, NT>(pipe, bias, h, in, [&](auto m_, f32x16(&acc)[NT]) {
         constexpr int m = decltype(m_)::value;
@@ -223,8 +223,8 @@ __device__ __forceinline__ void dense_act(Pipe& pipe, const NRF_LDS float* bias,
 }
 
 // head layer: one output tile, raw accumulators back to the caller
-template <class Mode, int KT, int NT>
-__device__ __forceinline__ void dense_head(Pipe& pipe, const NRF_LDS float* bias, int h,
+template <class Mode, int KT, int NT, class P>
+__device__ __forceinline__ void dense_head(P& pipe, const NRF_LDS float* bias, int h,
                                            const typename Mode::Act (&in)[KT][NT], f32x16 (&out)[NT]) {
     dense<Mode, KT, 1, NT>(pipe, bias, h, in, [&](auto, f32x16(&acc)[NT]) {
 #pragma unroll

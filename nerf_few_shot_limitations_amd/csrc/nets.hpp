@@ -69,7 +69,8 @@ struct NetV1 {
     static constexpr bool kNeedsDir = false;
     typedef typename Mode::Act Act;
 
-    __device__ static __forceinline__ void eval(Pipe& pipe, const NRF_LDS float* bias, int h, int n_layers,
+    template <class P>
+    __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
                                                 const Act (&enc)[KT0][NT], const Act (&)[1][NT], float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
         dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);
@@ -104,7 +105,8 @@ struct NetV2 {
     typedef typename Mode::Act Act;
 
     // density_head, feature_head, colour layers; X = trunk output, Y = scratch of the same shape
-    __device__ static __forceinline__ void tail(Pipe& pipe, const NRF_LDS float* bias, int h, const Act (&X)[HT][NT],
+    template <class P>
+    __device__ static __forceinline__ void tail(P& pipe, const NRF_LDS float* bias, int h, const Act (&X)[HT][NT],
                                                 Act (&Y)[HT][NT], const Act (&dir)[1][NT], float (&out4)[NT][4]) {
         f32x16 dens[NT];
         dense_head<Mode, HT, NT>(pipe, bias, h, X, dens);
@@ -128,7 +130,8 @@ struct NetV2 {
         }
     }
 
-    __device__ static __forceinline__ void eval(Pipe& pipe, const NRF_LDS float* bias, int h, int n_layers,
+    template <class P>
+    __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
                                                 const Act (&enc)[KT0][NT], const Act (&dir)[1][NT], float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
         dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);

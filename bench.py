@@ -6,10 +6,10 @@
 Workload (BASELINE.json metric): synthetic 800x800 camera frames, 64 samples per ray, the 8x256
 NeRF MLP (nerf_model.NeRFMLP, 951 808 FLOP per ray-sample), deterministic random-init weights
 ("solid" scene; early ray termination OFF, so every one of the R*S samples is evaluated), bf16 MFMA.  One step renders
-n_gpus frames: every frame's rays are sharded by contiguous pixel band over the ranks (rank r
-renders rays [r*HW/N, (r+1)*HW/N) of every frame -> per-GPU work is one frame's worth of rays,
-weak scaling) and the finished bands are exchanged with ONE RCCL all_gather per step so that
-every rank holds all frames.  Inputs are generated in-kernel (camera mode): nothing is read
+n_gpus views of the sensor: every view's rays are cut into 16-row pixel tiles dealt round-robin over
+the ranks (per-GPU work is one frame's worth of rays whatever N is: weak scaling); each rank renders
+its tiles of ALL views with ONE kernel launch and the finished tiles are exchanged with ONE RCCL
+all_gather per step so that every rank holds all frames.  Inputs are generated in-kernel (camera mode): nothing is read
 from the host in the timed region.
 
 The JSON line also carries
@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--net", default="v1", choices=["v1", "v2"])
     ap.add_argument("--scene", default="solid", choices=["fog", "solid"])
     ap.add_argument("--ert", type=float, default=0.0)
+    ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
     args = ap.parse_args()
 
@@ -53,12 +54,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # rehearsal knobs (one-GPU box): NERF_BENCH_FORCE_DEVICE=0 puts every rank on one card, NERF_BENCH_BACKEND=gloo
+    # exchanges through host memory; the driver's multi-GPU runs use neither (one rank per GPU, RCCL).
+    force = os.environ.get("NERF_BENCH_FORCE_DEVICE")
+    dev_index = int(force) if force is not None else local_rank
+    backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import nerf_few_shot_limitations_amd as N
     from oracle import nerf_oracle as O               # cpu_baseline / parity legs only
@@ -77,32 +86,37 @@ def main():
     model = model.to(dev).eval()
     flops_per_sample = model.flops_per_sample()
 
+    # one step = `world` views of the same sensor (the camera orbits the scene), tile-sharded over the ranks
+    import math
+    from nerf_few_shot_limitations_amd import tiles
     n_frames = world
-    band = (H * W + world - 1) // world               # rays of each frame this rank renders
-    b0 = rank * band
-    b1 = min(b0 + band, H * W)
-    local = torch.zeros((n_frames, band, 4), dtype=torch.float32, device=dev)       # rgb + depth per ray
-    rgb_buf = torch.empty((band, 3), dtype=torch.float32, device=dev)
-    depth_buf = torch.empty((band,), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world, n_frames, band, 4), dtype=torch.float32, device=dev) if world > 1 else None
+    poses = []
+    for v in range(n_frames):
+        th = 2 * math.pi * v / 8
+        rz = torch.tensor([[math.cos(th), -math.sin(th), 0, 0], [math.sin(th), math.cos(th), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
+        poses.append(rz @ c2w)
+    poses = torch.stack(poses)
+    tile_rays = args.tile_rows * W
+    job = tiles.TileJob(model, H, W, focal, poses, 2.0, 6.0, S, rank, world, tile_rays, ert_eps=args.ert, device=dev)
     ev = []
 
     def step(timed):
-        for f in range(n_frames):
-            if timed:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=b0, ray_end=b1, ert_eps=args.ert,
-                            device=dev, out_rgb=rgb_buf[: b1 - b0], out_depth=depth_buf[: b1 - b0])
-            if timed:
-                e1.record()
-                ev.append((e0, e1))
-            local[f, : b1 - b0, :3] = rgb_buf[: b1 - b0]
-            local[f, : b1 - b0, 3] = depth_buf[: b1 - b0]
-        if world > 1:
-            dist.all_gather_into_tensor(gathered.view(-1), local.view(-1))
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        job.launch()                                   # ONE render kernel launch: this rank's tiles of all views
+        if timed:
+            e1.record()
+            ev.append((e0, e1))
+        local = job.pack()
+        if world == 1:
+            return local
+        if backend != "nccl":
+            return tiles.gather_frames(local.cpu(), H * W, tile_rays)
+        return tiles.gather_frames(local, H * W, tile_rays)                            # ONE all_gather (RCCL)
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -117,12 +131,12 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
-    samples_per_launch = (b1 - b0) * S
+    samples_per_launch = job.rays_per_launch * S
     samples_per_step = n_frames * H * W * S                     # all ranks together
     value = samples_per_step * args.steps / dt / 1e6
     achieved = samples_per_launch * flops_per_sample / (kernel_ms * 1e-3) / 1e12
@@ -133,9 +147,9 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.mode, "data": "synthetic",
         "config": {"workload": f"{H}x{W} camera frame x {S} samples/ray, NeRFMLP {args.net} 8x256, scene {args.scene}, "
-                               f"{n_frames} frame(s)/step band-sharded over {world} GPU(s) + all_gather",
-                   "rays_per_gpu_per_step": n_frames * (b1 - b0), "samples_per_ray": S, "ert_eps": args.ert,
-                   "flops_per_sample": flops_per_sample, "parallelism": f"pixel-band x{world}"},
+                               f"{n_frames} view(s)/step, {args.tile_rows}-row pixel tiles dealt round-robin over {world} GPU(s), one launch + one all_gather per step",
+                   "rays_per_gpu_per_step": job.rays_per_launch, "samples_per_ray": S, "ert_eps": args.ert,
+                   "flops_per_sample": flops_per_sample, "parallelism": f"pixel-tile x{world}"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.mode], "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": None,
                      "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ev)},

@@ -131,6 +131,20 @@ int nrf_render_camera(const nrf_model* m, int H, int W, float focal, const float
                       int64_t ray_begin, int64_t ray_end, const nrf_render_opts* opts,
                       float* rgb, float* depth, float* weights, float* z_vals, void* stream);
 
+/* Pixel-tile sharded, multi-view form (no reference counterpart; the batch
+ * of views is the reference's loop over test views, train.py:304).  The image's rays are cut into
+ * tiles of tile_rays consecutive ray ids; ONE launch renders, for each of the n_cams (<= 8) poses
+ * c2w[c*12 .. c*12+11] of the same HxW/focal sensor, tiles first_tile, first_tile+tile_step, ...
+ * (n_tiles of them, e.g. first_tile=rank, tile_step=world).  Output row
+ * (c*n_tiles + k)*tile_rays + j holds ray (first_tile + k*tile_step)*tile_rays + j of view c; rows
+ * whose ray id falls beyond H*W repeat the last ray (padding, so every rank's buffer has the same
+ * shape for the gather).  Per-ray arithmetic is identical to nrf_render_camera: shards reassemble
+ * bit-exactly. */
+int nrf_render_cameras_tiles(const nrf_model* m, int H, int W, float focal, const float* c2w, int n_cams,
+                             int64_t tile_rays, int64_t first_tile, int64_t tile_step, int64_t n_tiles,
+                             const nrf_render_opts* opts,
+                             float* rgb, float* depth, float* weights, float* z_vals, void* stream);
+
 /* ---- staged entry points (one reference leaf each; used by the drop-in
  *      Python surface and by the stage-wise parity tests) ------------------- */
 

@@ -59,6 +59,8 @@ SIGNATURES = {
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_render_camera": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float * 12, C.c_int64, C.c_int64,
                                     C.POINTER(nrf_render_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_render_cameras_tiles": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64,
+                                           C.c_int64, C.POINTER(nrf_render_opts), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_get_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float * 12, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_sample_along_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),

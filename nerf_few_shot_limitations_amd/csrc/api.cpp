@@ -204,6 +204,7 @@ int nrf_render_rays(const nrf_model* m, const float* rays_o, const float* rays_d
     if ((int64_t)opts->n_samples * n_rays > (int64_t)1 << 40) return fail(NRF_EINVAL, "ray-sample count too large");
     nrf::RenderArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.camera_mode = 0; a.ray_begin = 0; a.n_rays = n_rays;
+    a.n_cams = 1; a.rays_per_cam = n_rays; a.tile_rays = n_rays; a.tile_stride = 0;
     fill_common(a, opts, rgb, depth, weights, z_vals);
     std::string err;
     if (m->arch.net == NRF_NET_V3 && !make_dino(opts->dino, m->arch.dino_dim, a.dino, err)) return fail(NRF_EINVAL, err);
@@ -223,7 +224,35 @@ int nrf_render_camera(const nrf_model* m, int H, int W, float focal, const float
     const int rc = check_opts(opts);
     if (rc != NRF_OK) return rc;
     nrf::RenderArgs a{};
-    a.camera_mode = 1; a.cam = make_camera(H, W, focal, c2w); a.ray_begin = ray_begin; a.n_rays = ray_end - ray_begin;
+    a.camera_mode = 1; a.n_cams = 1; a.cams[0] = make_camera(H, W, focal, c2w); a.ray_begin = ray_begin; a.n_rays = ray_end - ray_begin;
+    a.rays_per_cam = a.n_rays; a.tile_rays = a.n_rays; a.tile_stride = 0;
+    fill_common(a, opts, rgb, depth, weights, z_vals);
+    std::string err;
+    if (m->arch.net == NRF_NET_V3 && !make_dino(opts->dino, m->arch.dino_dim, a.dino, err)) return fail(NRF_EINVAL, err);
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    const int r = nrf::launch_render(m->net, opts->mma_mode, a, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_render_cameras_tiles(const nrf_model* m, int H, int W, float focal, const float* c2w, int n_cams, int64_t tile_rays,
+                             int64_t first_tile, int64_t tile_step, int64_t n_tiles, const nrf_render_opts* opts, float* rgb, float* depth,
+                             float* weights, float* z_vals, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (H < 1 || W < 1 || !(focal > 0.0f) || !c2w) return fail(NRF_EINVAL, "bad camera");
+    if (n_cams < 1 || n_cams > nrf::kMaxCams) return fail(NRF_EINVAL, "n_cams must be in 1..8 per call");
+    if (tile_rays < 1 || first_tile < 0 || tile_step < 1 || n_tiles < 0) return fail(NRF_EINVAL, "bad tile description");
+    if (n_tiles == 0) return NRF_OK;
+    if (first_tile * tile_rays >= (int64_t)H * W) return fail(NRF_EINVAL, "first tile lies outside the image");
+    if (!rgb || !depth) return fail(NRF_EINVAL, "nrf_render_cameras_tiles: null output pointer");
+    const int rc = check_opts(opts);
+    if (rc != NRF_OK) return rc;
+    if (opts->t_rand) return fail(NRF_EINVAL, "tile rendering draws its jitter from the counter RNG (t_rand must be NULL)");
+    nrf::RenderArgs a{};
+    a.camera_mode = 1; a.n_cams = n_cams;
+    for (int c = 0; c < n_cams; ++c) a.cams[c] = make_camera(H, W, focal, c2w + 12 * c);
+    a.ray_begin = first_tile * tile_rays; a.rays_per_cam = n_tiles * tile_rays; a.n_rays = a.rays_per_cam * n_cams;
+    a.tile_rays = tile_rays; a.tile_stride = tile_step * tile_rays;
     fill_common(a, opts, rgb, depth, weights, z_vals);
     std::string err;
     if (m->arch.net == NRF_NET_V3 && !make_dino(opts->dino, m->arch.dino_dim, a.dino, err)) return fail(NRF_EINVAL, err);

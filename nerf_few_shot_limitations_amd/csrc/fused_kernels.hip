@@ -52,6 +52,23 @@ __device__ __forceinline__ void load_bias_table(NRF_LDS float* bias, const float
     __syncthreads();
 }
 
+// local ray index -> (view of the batch, global ray id inside that view); pixel-tile sharding: SURVEY.md section 8e
+__device__ __forceinline__ int64_t global_ray(const RenderArgs& a, int64_t i, int& cam) {
+    cam = 0;
+    if (!a.camera_mode) return i;
+    if (a.n_cams > 1) {
+        cam = (int)(i / a.rays_per_cam);
+        i -= (int64_t)cam * a.rays_per_cam;
+    }
+    int64_t g = a.ray_begin + i;
+    if (a.tile_rays < a.rays_per_cam) {
+        const int64_t k = i / a.tile_rays;
+        g = a.ray_begin + k * a.tile_stride + (i - k * a.tile_rays);
+    }
+    const int64_t last = (int64_t)a.cams[0].H * a.cams[0].W - 1;
+    return g < last ? g : last;
+}
+
 // ---------------------------------------------------------------------------------------------
 // fused renderer
 // ---------------------------------------------------------------------------------------------
@@ -87,7 +104,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             const int64_t r = tile * TILE + wave * (32 * NT) + 32 * n + c;
             rid[n] = r < a.n_rays ? r : a.n_rays - 1;
             if (a.camera_mode) {
-                camera_ray(a.cam, a.ray_begin + rid[n], o[n], d[n]);
+                int ci;
+                const int64_t g = global_ray(a, rid[n], ci);
+                camera_ray(a.cams[ci], g, o[n], d[n]);
             } else {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { o[n][k] = a.rays_o[rid[n] * 3 + k]; d[n][k] = a.rays_d[rid[n] * 3 + k]; }
@@ -113,7 +132,14 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 
         auto z_ray = [&](int64_t ray, int s) -> float {
             if (!a.perturb) return ladder_z(lad, s);
-            const float u = a.t_rand ? a.t_rand[ray * S + s] : counter_uniform(a.seed, (uint64_t)(a.ray_begin + ray), (uint32_t)s);
+            float u;
+            if (a.t_rand) {
+                u = a.t_rand[ray * S + s];
+            } else {
+                int ci;
+                const int64_t g = global_ray(a, ray, ci);
+                u = counter_uniform(a.seed + (uint64_t)ci * 0x51ED27ull, (uint64_t)g, (uint32_t)s);
+            }
             return ladder_z_jitter(lad, s, u);
         };
 

@@ -10,6 +10,8 @@
 
 namespace nrf {
 
+constexpr int kMaxCams = 8;
+
 // device-side image of one nrf_model
 struct DeviceNet {
     nrf_arch arch;
@@ -35,9 +37,13 @@ struct RenderArgs {
     const float* rays_o;
     const float* rays_d;
     int camera_mode;
-    Camera cam;
+    int n_cams;             // camera mode: a batch of up to kMaxCams views of one HxW sensor rendered by ONE launch
+    int64_t rays_per_cam;   // local rays [c*rays_per_cam, (c+1)*rays_per_cam) belong to cams[c]
+    Camera cams[8];
     int64_t ray_begin;
     int64_t n_rays;
+    int64_t tile_rays;      // camera mode: local ray i is global ray ray_begin + (i / tile_rays) * tile_stride + i % tile_rays,
+    int64_t tile_stride;    // clamped to the image (tile_rays >= n_rays: one contiguous range)
     // sampling
     float near, far;
     int n_samples, lindisp, perturb;

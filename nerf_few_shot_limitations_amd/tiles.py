@@ -1,0 +1,153 @@
+"""Multi-GPU frames: pixel-tile sharding + one collective at frame end.
+
+Rays are independent, so there is no exchange while rendering.  The image's H*W ray ids are cut
+into tiles of `tile_rays` consecutive ids dealt round-robin (tile t -> rank t mod world: with early
+ray termination the cost of a tile is scene dependent, small interleaved tiles balance it); every
+rank renders its tiles -- of a whole batch of views -- with ONE nrf_render_cameras_tiles launch into a
+(views, tiles_per_rank*tile_rays, 4) buffer [r,g,b,depth] and the buffers are exchanged with ONE all_gather (backend "nccl" = RCCL over
+xGMI on the GPU box; "gloo" in the CPU tests).  The partition / reassembly arithmetic lives in plain
+functions so that it is testable without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+from .ray_sampler import _c2w12
+
+
+def tile_plan(n_rays: int, world: int, tile_rays: int):
+    """(tiles_total, tiles_per_rank): every rank gets the same count (the tail is padding)."""
+    tiles_total = (n_rays + tile_rays - 1) // tile_rays
+    per_rank = (tiles_total + world - 1) // world
+    return tiles_total, per_rank
+
+
+def local_ray_ids(rank: int, world: int, n_rays: int, tile_rays: int) -> torch.Tensor:
+    """Global ray id of every row of rank's local buffer (padding rows clamp to the last ray) --
+    the integer contract nrf_render_camera_tiles implements."""
+    _, per_rank = tile_plan(n_rays, world, tile_rays)
+    k = torch.arange(per_rank, dtype=torch.int64)[:, None]
+    j = torch.arange(tile_rays, dtype=torch.int64)[None, :]
+    ids = (rank + k * world) * tile_rays + j
+    return ids.clamp_(max=n_rays - 1).reshape(-1)
+
+
+def reassemble(gathered: torch.Tensor, n_rays: int, world: int, tile_rays: int) -> torch.Tensor:
+    """gathered (world, per_rank*tile_rays, C) -> frame (n_rays, C) in ray-id order."""
+    _, per_rank = tile_plan(n_rays, world, tile_rays)
+    c = gathered.shape[-1]
+    g = gathered.reshape(world, per_rank, tile_rays, c).permute(1, 0, 2, 3)        # tile t = k*world + rank
+    return g.reshape(per_rank * world * tile_rays, c)[:n_rays]
+
+
+def gather_frame(local: torch.Tensor, n_rays: int, tile_rays: int, group=None) -> torch.Tensor:
+    """All ranks contribute their (per_rank*tile_rays, C) buffer; every rank gets the (n_rays, C) frame."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return reassemble(local[None], n_rays, 1, tile_rays)
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out.view(-1), local.contiguous().view(-1), group=group)
+    return reassemble(out, n_rays, world, tile_rays)
+
+
+def _poses12(c2w) -> "C.Array":
+    """(V,4,4)/(V,3,4)/(4,4)/(3,4) poses -> V*12 floats (first three rows of each)."""
+    m = torch.as_tensor(c2w).detach().to("cpu", torch.float32)
+    if m.dim() == 2:
+        m = m[None]
+    if m.shape[1:] not in ((4, 4), (3, 4)):
+        raise ValueError(f"poses must be (V,4,4) or (V,3,4), got {tuple(m.shape)}")
+    flat = m[:, :3, :4].reshape(-1).tolist()
+    return (C.c_float * len(flat))(*flat), m.shape[0]
+
+
+class TileJob:
+    """Everything one rank needs to render its tiles of a batch of views, prepared once:
+    `launch()` enqueues exactly the render kernel(s); `pack()` interleaves rgb+depth into the gather buffer."""
+
+    def __init__(self, model, H, W, focal, c2w, near, far, N_samples, rank, world, tile_rays, perturb=False, seed=0, lindisp=False,
+                 ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, device=None):
+        from .renderer import _opts, make_dino
+        L.require_gpu()
+        self.H, self.W, self.focal = int(H), int(W), float(focal)
+        self.n_rays = self.H * self.W
+        self.rank, self.world, self.tile_rays = int(rank), int(world), int(tile_rays)
+        self.tiles_total, self.per_rank = tile_plan(self.n_rays, self.world, self.tile_rays)
+        if device is None:
+            p = next(model.parameters())
+            device = p.device if p.is_cuda else torch.device("cuda", torch.cuda.current_device())
+        self.device = torch.device(device)
+        self._dn = self._keep = None
+        if model.net == L.NRF_NET_V3:
+            self._dn, self._keep = make_dino(**dino)
+        self.opts = _opts(near, far, N_samples, perturb, None, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode,
+                          self._dn, self.device)
+        self.model = model
+        self.poses, self.V = _poses12(c2w)
+        self.n_real = len(range(self.rank, self.tiles_total, self.world))   # tiles that start inside the image; the rest is padding
+        with torch.cuda.device(self.device):
+            self.rgb = torch.empty((self.V, self.n_real * self.tile_rays, 3), dtype=torch.float32, device=self.device)
+            self.depth = torch.empty((self.V, self.n_real * self.tile_rays), dtype=torch.float32, device=self.device)
+            self.buf = torch.zeros((self.V, self.per_rank * self.tile_rays, 4), dtype=torch.float32, device=self.device)
+
+    @property
+    def rays_per_launch(self):
+        return min(8, self.V) * self.n_real * self.tile_rays
+
+    def launch(self):
+        h = self.model.handle(self.device)
+        with torch.cuda.device(self.device):
+            for v0 in range(0, self.V, 8):
+                nv = min(8, self.V - v0)
+                sub = (C.c_float * (12 * nv)).from_buffer(self.poses, 4 * 12 * v0)
+                L.check(L.lib().nrf_render_cameras_tiles(h, self.H, self.W, self.focal, C.cast(sub, C.c_void_p), nv, self.tile_rays,
+                                                         self.rank, self.world, self.n_real, C.byref(self.opts),
+                                                         L.ptr(self.rgb[v0:v0 + nv]), L.ptr(self.depth[v0:v0 + nv]), None, None,
+                                                         L.stream_ptr()))
+
+    def pack(self):
+        n = self.n_real * self.tile_rays
+        self.buf[:, :n, :3] = self.rgb
+        self.buf[:, :n, 3] = self.depth
+        return self.buf
+
+
+def render_tiles(model, H, W, focal, c2w, near, far, N_samples, rank, world, tile_rays, **kw):
+    """This rank's tiles of a batch of V views (c2w (V,4,4), or one (4,4) pose) -> (V, per_rank*tile_rays, 4) = [r,g,b,depth].
+    Up to 8 views go into one kernel launch."""
+    job = TileJob(model, H, W, focal, c2w, near, far, N_samples, rank, world, tile_rays, **kw)
+    job.launch()
+    return job.pack()
+
+
+def gather_frames(local: torch.Tensor, n_rays: int, tile_rays: int, group=None) -> torch.Tensor:
+    """local (V, per_rank*tile_rays, C) on every rank -> (V, n_rays, C) on every rank with ONE all_gather."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    V = local.shape[0]
+    if world == 1:
+        g = local[None]
+    else:
+        g = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(g.view(-1), local.contiguous().view(-1), group=group)
+    return torch.stack([reassemble(g[:, v], n_rays, world, tile_rays) for v in range(V)])
+
+
+def render_frame_sharded(model, H, W, focal, c2w, near, far, N_samples=64, tile_rows=16, group=None, **kw):
+    """Full frame(s) on every rank: (rgb (H,W,3), depth (H,W)) -- with a leading view axis if c2w is a batch.
+    One launch (per 8 views) + one all_gather per rank."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    tile_rays = int(tile_rows) * int(W)
+    local = render_tiles(model, H, W, focal, c2w, near, far, N_samples, rank, world, tile_rays, **kw)
+    frames = gather_frames(local, int(H) * int(W), tile_rays, group)
+    rgb, depth = frames[..., :3].reshape(-1, H, W, 3), frames[..., 3].reshape(-1, H, W)
+    if torch.as_tensor(c2w).dim() == 2:
+        return rgb[0], depth[0]
+    return rgb, depth

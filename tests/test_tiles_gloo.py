@@ -1,0 +1,68 @@
+"""N>1 path on CPU: the pixel-tile partition and the all_gather reassembly (gloo, world_size 2 and 3),
+with ray ids standing in for rendered pixels -- the integer contract of SURVEY.md section 8e."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nerf_few_shot_limitations_amd import tiles
+
+
+def test_tile_plan_covers_every_ray_exactly_once():
+    for n_rays, world, tile_rays in [(100, 1, 16), (640000, 8, 12800), (1000, 3, 64), (37 * 53, 4, 53 * 5), (7, 8, 3)]:
+        seen = torch.zeros(n_rays, dtype=torch.int64)
+        total, per_rank = tiles.tile_plan(n_rays, world, tile_rays)
+        assert per_rank * world >= total
+        for r in range(world):
+            ids = tiles.local_ray_ids(r, world, n_rays, tile_rays)
+            assert ids.shape[0] == per_rank * tile_rays
+            raw = (r + torch.arange(per_rank)[:, None] * world) * tile_rays + torch.arange(tile_rays)[None, :]
+            real = raw.reshape(-1) < n_rays
+            seen.index_add_(0, ids[real], torch.ones(int(real.sum()), dtype=torch.int64))
+        assert torch.all(seen == 1)
+        # reassemble() inverts the partition
+        g = torch.stack([tiles.local_ray_ids(r, world, n_rays, tile_rays) for r in range(world)]).unsqueeze(-1).float()
+        frame = tiles.reassemble(g, n_rays, world, tile_rays)
+        assert torch.equal(frame[:, 0].long(), torch.arange(n_rays))
+
+
+def _worker(rank, world, port, n_rays, tile_rays, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ids = tiles.local_ray_ids(rank, world, n_rays, tile_rays)
+        local = torch.stack([ids.float(), ids.float() * 2, ids.float() + 0.5, -ids.float()], -1)     # "rendered" [r,g,b,depth]
+        frame = tiles.gather_frame(local, n_rays, tile_rays)
+        want = torch.arange(n_rays).float()
+        ok = (frame.shape == (n_rays, 4) and torch.equal(frame[:, 0], want) and torch.equal(frame[:, 1], want * 2)
+              and torch.equal(frame[:, 3], -want))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,n_rays,tile_rays", [(2, 40 * 30, 30 * 4), (3, 1000, 64)])
+def test_gather_frame_gloo(world, n_rays, tile_rays):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_rays, tile_rays, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=10) for _ in range(world))
+    assert res == {r: True for r in range(world)}

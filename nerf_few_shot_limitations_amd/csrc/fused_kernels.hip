@@ -24,6 +24,7 @@ struct NetArgs {
     uint32_t n_chunks;
     int n_bias;
     int n_layers;
+    uint32_t ablate;
 };
 
 struct RenderKArgs {
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     load_bias_table(bias, P.net.bias, P.net.n_bias);
 
     Pipe<WAVES> pipe;
-    pipe.init(P.net.stream, P.net.n_chunks, lds);
+    pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
     const RenderArgs& a = P.a;
@@ -235,7 +236,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
     Pipe<WAVES> pipe;
-    pipe.init(P.net.stream, P.net.n_chunks, lds);
+    pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
     const int own = (NT == 2) ? h : 0;
     const bool owner = h < NT;
@@ -309,6 +310,8 @@ int prepare(K kernel, std::string& err) {
 NetArgs net_args(const DeviceNet& net, int mode) {
     NetArgs n;
     n.stream = net.stream[mode]; n.bias = net.bias; n.n_chunks = net.n_chunks[mode]; n.n_bias = net.n_bias; n.n_layers = net.arch.n_layers;
+    static const uint32_t ablate = [] { const char* e = getenv("NRF_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
+    n.ablate = ablate;   // timing experiments only: results are wrong when set
     return n;
 }
 

@@ -28,6 +28,25 @@ namespace nrf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) short i16x2;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+// two fp32 -> one packed 16-bit pair (v_cvt_pk_*), optional ReLU as a signed-integer max with 0 on the pair
+// (v_pk_max_i16: a negative float has its sign bit set, i.e. is a negative int16) -- one VALU op per two
+// activations instead of an fp32 max (+ canonicalisation) per element
+template <class V2, bool RELU>
+__device__ __forceinline__ int pack_pair(float a, float b) {
+    const f32x2 ab = {a, b};
+    i16x2 q = __builtin_bit_cast(i16x2, __builtin_convertvector(ab, V2));
+    if (RELU) {
+        const i16x2 zero = {0, 0};
+        q = __builtin_elementwise_max(q, zero);
+    }
+    return __builtin_bit_cast(int, q);
+}
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
@@ -51,21 +70,33 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ---------------------------------------------------------------------------
 // weight streamer
 // ---------------------------------------------------------------------------
-// WAVES = waves of the workgroup that share the stream (4: one per SIMD, or 8: two per SIMD)
+// WAVES = waves of the workgroup that share the stream (4: one per SIMD, or 8: two per SIMD).
+//
+// Ring protocol.  Chunk X of the (periodic) stream lives in slot X mod kSlots.  acquire(X):
+//   1. s_waitcnt vmcnt(kFragsPerWave*(kAhead-1)): this wave's own part of chunk X has landed (the kAhead-1
+//      younger chunks X+1..X+kAhead-1 may still be in flight);
+//   2. raw s_barrier: every wave's part has landed, and every wave has issued all its reads of chunk X-2;
+//   3. issue chunk X+kAhead into slot (X+kAhead) mod kSlots == slot of chunk X-2 (kAhead = kSlots-2).
+// acquire(X) is called a few fragments BEFORE the reads of chunk X-1 are finished (dense() below), so that the
+// first fragments of chunk X are already in flight while the last MFMAs of chunk X-1 run: that is why the
+// slot recycled at the barrier is the one two chunks back, not one.
 template <int WAVES>
 struct Pipe {
     static constexpr int kFragsPerWave = kChunkFrags / WAVES;    // glds instructions per wave per chunk
-    const NRF_GLB char* src;   // packed stream + wave*4 KiB + lane*16
+    static constexpr int kAhead = kSlots - 2;                    // chunks in flight / landed ahead of the reader
+    const NRF_GLB char* src;   // packed stream + wave*kFragsPerWave KiB + lane*16
     NRF_LDS char* ring;        // ring base (LDS)
-    NRF_LDS char* cur;         // current chunk + lane*16
+    NRF_LDS char* base[2];     // chunk bases (+ lane*16) by parity of the chunk's index inside the layer
     uint32_t n_chunks;         // chunks per MLP pass (the stream wraps)
     uint32_t issue_chunk;
     uint32_t issue_slot;
     uint32_t read_slot;
-    uint32_t wave_off;         // wave * 4 KiB (wave-uniform)
+    uint32_t wave_off;         // wave * kFragsPerWave KiB (wave-uniform)
     uint32_t lane_off;         // lane * 16
+    uint32_t ablate;           // timing experiments only (NRF_ABLATE): 1 = stop streaming after the first fill, 2 = no barriers
 
-    __device__ __forceinline__ void init(const void* stream, uint32_t chunks, NRF_LDS char* ring_base) {
+    __device__ __forceinline__ void init(const void* stream, uint32_t chunks, NRF_LDS char* ring_base, uint32_t ablate_flags = 0) {
+        ablate = ablate_flags;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane_off = (threadIdx.x & 63) * 16;
         wave_off = wave * (kFragsPerWave * kFragBytes);
@@ -73,7 +104,7 @@ struct Pipe {
         ring = ring_base;
         n_chunks = chunks;
         issue_chunk = 0; issue_slot = 0; read_slot = 0;
-        cur = ring_base + lane_off;
+        base[0] = base[1] = ring_base + lane_off;
     }
     __device__ __forceinline__ void issue_one() {
         const NRF_GLB char* g = src + (size_t)issue_chunk * kChunkBytes;
@@ -84,18 +115,17 @@ struct Pipe {
         issue_chunk = (issue_chunk + 1 == n_chunks) ? 0u : issue_chunk + 1;
         issue_slot = (issue_slot + 1 == (uint32_t)kSlots) ? 0u : issue_slot + 1;
     }
-    // fill the ring: kSlots-1 chunks in flight
+    // fill the ring: kAhead chunks in flight
     __device__ __forceinline__ void start() {
-        for (int k = 0; k < kSlots - 1; ++k) issue_one();
+        for (int k = 0; k < kAhead; ++k) issue_one();
     }
-    // make the next chunk readable, free the previous one, keep the ring full
-    __device__ __forceinline__ void acquire() {
-        // own part of the chunk has landed once at most (kSlots-2) younger chunks' loads are outstanding
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFragsPerWave * (kSlots - 2)) : "memory");
-        __builtin_amdgcn_s_barrier();     // every wave's part landed; every wave is done with the previous chunk
+    // make the next chunk of the stream readable through base[parity]
+    __device__ __forceinline__ void acquire(int parity) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFragsPerWave * (kAhead - 1)) : "memory");
+        if (!(ablate & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issue_one();                      // refill the slot that was just released
-        cur = ring + read_slot * kChunkBytes + lane_off;
+        if (!(ablate & 1)) issue_one();
+        base[parity] = ring + read_slot * kChunkBytes + lane_off;
         read_slot = (read_slot + 1 == (uint32_t)kSlots) ? 0u : read_slot + 1;
     }
     // all LDS-DMA must have landed before the workgroup gives its LDS back
@@ -118,12 +148,12 @@ struct ModeBF16 {
     __device__ static __forceinline__ Act to_act(const f32x16& v) {
         Act o;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            i32x4 w;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = v[8 * s + j];
-                o.f[s][j] = (__bf16)(RELU ? fmaxf(x, 0.0f) : x);
-            }
+            for (int j = 0; j < 4; ++j) w[j] = pack_pair<bf16x2, RELU>(v[8 * s + 2 * j], v[8 * s + 2 * j + 1]);
+            o.f[s] = __builtin_bit_cast(bf16x8, w);
+        }
         return o;
     }
 };
@@ -141,12 +171,12 @@ struct ModeF16 {
     __device__ static __forceinline__ Act to_act(const f32x16& v) {
         Act o;
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+            i32x4 w;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float x = v[8 * s + j];
-                o.f[s][j] = (_Float16)(RELU ? fmaxf(x, 0.0f) : x);
-            }
+            for (int j = 0; j < 4; ++j) w[j] = pack_pair<f16x2, RELU>(v[8 * s + 2 * j], v[8 * s + 2 * j + 1]);
+            o.f[s] = __builtin_bit_cast(f16x8, w);
+        }
         return o;
     }
 };
@@ -182,33 +212,54 @@ __device__ __forceinline__ void load_bias(f32x16& acc, const NRF_LDS float* bias
     }
 }
 
-// One Linear layer: out[m][n] (32 features x 32 samples each) = W * in + bias, for MT output
-// tiles, KT input tiles, NT sample tiles.  Consumes MT*KT*SUB fragments from the pipe (the host
-// pads every layer to whole chunks, so a layer always starts on a chunk boundary).
-// `fin(m, acc)` receives each finished tile's raw accumulators.
+// One Linear layer: out[m][n] (32 features x 32 samples each) = W * in + bias, for MT output tiles, KT input
+// tiles, NT sample tiles.  Consumes MT*KT*SUB fragments of the stream (the host pads every layer to whole
+// chunks, so a layer always starts on a chunk boundary).  `fin(m, acc)` receives each finished tile's raw
+// accumulators.  Fragment reads are software-pipelined kPrefetch deep (LDS latency would otherwise sit in front
+// of every MFMA) and the next chunk is acquired kPrefetch fragments before the current one is used up, so
+// the read stream never stops inside a layer.
+constexpr int kPrefetch = 4;
+constexpr int kEpilogueAt = 3;   // the epilogue of tile m-1 runs after this many fragments of tile m have been issued
+
 template <class Mode, int KT, int MT, int NT, class P, class Fin>
 __device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,
                                       const typename Mode::Act (&in)[KT][NT], Fin&& fin) {
-    static_for<MT>([&](auto m_) {
-        constexpr int m = decltype(m_)::value;
-        f32x16 acc[NT];
-        load_bias(acc[0], bias + 32 * m, h);
+    constexpr int PER_M = KT * Mode::SUB;
+    constexpr int NF = MT * PER_M;
+    constexpr int PF = NF < kPrefetch ? NF : kPrefetch;
+    constexpr int EPI = PER_M > kEpilogueAt ? kEpilogueAt : PER_M - 1;
+    typedef typename Mode::frag_t frag_t;
+    frag_t fr[PF];
+    auto read = [&](auto g_) -> frag_t {
+        constexpr int g = decltype(g_)::value;
+        if constexpr (g % kChunkFrags == 0) pipe.acquire((g / kChunkFrags) & 1);
+        return *(const NRF_LDS frag_t*)(pipe.base[(g / kChunkFrags) & 1] + (g % kChunkFrags) * kFragBytes);
+    };
+    static_for<PF>([&](auto i_) { fr[decltype(i_)::value] = read(i_); });
+    // two accumulator sets: while tile m accumulates into acc[m&1], the finished tile m-1 sits in acc[(m-1)&1]
+    // until its MFMAs have drained (no s_nop bubble), is handed to fin(), and the set is re-armed with the
+    // bias of tile m+1 -- so neither the epilogue nor the bias reads sit between two MFMAs
+    f32x16 acc[2][NT];
+    load_bias(acc[0][0], bias, h);
 #pragma unroll
-        for (int n = 1; n < NT; ++n) acc[n] = acc[0];
-        static_for<KT>([&](auto t_) {
-            constexpr int t = decltype(t_)::value;
-            static_for<Mode::SUB>([&](auto s_) {
-                constexpr int s = decltype(s_)::value;
-                constexpr int f = (m * KT + t) * Mode::SUB + s;
-                if constexpr (f % kChunkFrags == 0) pipe.acquire();
-                const typename Mode::frag_t a =
-                    *(const NRF_LDS typename Mode::frag_t*)(pipe.cur + (f % kChunkFrags) * kFragBytes);
+    for (int n = 1; n < NT; ++n) acc[0][n] = acc[0][0];
+    static_for<NF>([&](auto f_) {
+        constexpr int f = decltype(f_)::value;
+        constexpr int m = f / PER_M, rem = f % PER_M, t = rem / Mode::SUB, s = rem % Mode::SUB;
+        const frag_t a = fr[f % PF];
 #pragma unroll
-                for (int n = 0; n < NT; ++n) Mode::mma(acc[n], a, in[t][n], s);
-            });
-        });
-        fin(m_, acc);
+        for (int n = 0; n < NT; ++n) Mode::mma(acc[m & 1][n], a, in[t][n], s);
+        if constexpr (f + PF < NF) fr[f % PF] = read(std::integral_constant<int, f + PF>{});
+        if constexpr (rem == EPI) {
+            if constexpr (m > 0) fin(std::integral_constant<int, m - 1>{}, acc[(m - 1) & 1]);
+            if constexpr (m + 1 < MT) {
+                load_bias(acc[(m + 1) & 1][0], bias + 32 * (m + 1), h);
+#pragma unroll
+                for (int n = 1; n < NT; ++n) acc[(m + 1) & 1][n] = acc[(m + 1) & 1][0];
+            }
+        }
     });
+    fin(std::integral_constant<int, MT - 1>{}, acc[(MT - 1) & 1]);
 }
 
 // layer with an activation, producing the next layer's operand tiles

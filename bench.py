@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--net", default="v1", choices=["v1", "v2"])
+    ap.add_argument("--net", default="v1", choices=["v1", "v2", "v3"])
     ap.add_argument("--scene", default="solid", choices=["fog", "solid"])
     ap.add_argument("--ert", type=float, default=0.0)
     ap.add_argument("--tile-rows", type=int, default=16)
@@ -75,14 +75,20 @@ def main():
     H, W, S = args.height, args.width, args.samples
     c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
     focal = O.focal_for(W)
-    seed = 0 if args.net == "v1" else 1
+    seed = {"v1": 0, "v2": 1, "v3": 2}[args.net]
     p = O.make_weights(args.net, seed, args.scene)
+    dino = None
     if args.net == "v1":
         model = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=args.mode)
         model.load_state_dict(p)
-    else:
+    elif args.net == "v2":
         model = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=args.mode)
         model.load_state_dict(p, strict=False)
+    else:
+        model = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=args.mode)
+        model.load_state_dict(p, strict=False)
+        fm = torch.from_numpy(O.uniform01(7, 28 * 28 * 64).reshape(1, 28, 28, 64) * 2 - 1)
+        dino = dict(features=fm, pose=c2w, focal=focal, H=H, W=W)
     model = model.to(dev).eval()
     flops_per_sample = model.flops_per_sample()
 
@@ -97,7 +103,7 @@ def main():
         poses.append(rz @ c2w)
     poses = torch.stack(poses)
     tile_rays = args.tile_rows * W
-    job = tiles.TileJob(model, H, W, focal, poses, 2.0, 6.0, S, rank, world, tile_rays, ert_eps=args.ert, device=dev)
+    job = tiles.TileJob(model, H, W, focal, poses, 2.0, 6.0, S, rank, world, tile_rays, ert_eps=args.ert, device=dev, dino=dino)
     ev = []
 
     def step(timed):
@@ -170,15 +176,15 @@ def main():
         ref = None
         for _ in range(3):
             tc = time.perf_counter()
-            ref = O.render_rays(p, args.net, ro, rd, 2.0, 6.0, S, chunk=2048)
+            ref = O.render_rays(p, args.net, ro, rd, 2.0, 6.0, S, chunk=2048, dino=dino)
             el = time.perf_counter() - tc
             best = el if best is None else min(best, el)
             print(f"[bench] cpu oracle pass: {el:.2f} s", file=sys.stderr, flush=True)
         out["cpu_baseline"] = {"value": round(rows * W * S / best / 1e6, 4), "unit": "M ray-samples/s", "cores": threads,
                                "kind": "port", "sample": f"{rows} rows ({rows * W} rays x {S} samples) of the same {H}x{W} frame, "
                                                           f"torch fp32 CPU, chunk 2048 rays, best of 3"}
-        rgb_b, depth_b = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, ert_eps=args.ert, device=dev)
-        rgb32, depth32 = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f32", device=dev)
+        rgb_b, depth_b = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, ert_eps=args.ert, device=dev, dino=dino)
+        rgb32, depth32 = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f32", device=dev, dino=dino)
         torch.cuda.synchronize()
         out["parity"] = {
             "band_rows": rows,

@@ -150,7 +150,7 @@ int nrf_model_create(nrf_model** out, int device, const nrf_arch* arch, const nr
     std::string err;
     if (!copy_linears(linears, n_linear, m->lin, err) || !nrf::make_plan(*arch, m->lin, m->plan, err)) {
         delete m;
-        return fail(arch->net == NRF_NET_V3 ? NRF_EUNSUPPORTED : NRF_EINVAL, err);
+        return fail(NRF_EINVAL, err);
     }
     DeviceGuard guard(device);
     if (!guard.ok) { delete m; return fail(NRF_EHIP, "cannot select device " + std::to_string(device)); }

@@ -38,6 +38,7 @@ struct ForwardKArgs {
     const float* x_enc;      // V1: (P, pe_dim)
     const float* pos;        // V2/V3: (P,3)
     const float* dir;        // V2/V3: (P,3)
+    const float* dino;       // V3: (P,64)
     int64_t n;
     float* out4;             // V1: (P,4)
     float* rgb;              // V2/V3: (P,3)
@@ -156,20 +157,29 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 #pragma unroll
             for (int n = 0; n < NT; ++n) zn[n] = last ? 0.0f : z_ray(rid[n], s + 1);
 
-            Act enc[KT0][NT];
+            // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
+            auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                float p[3];
+                for (int n = 0; n < NT; ++n) {
+                    float p[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) p[k] = point_on_ray(o[n][k], d[n][k], zc[n]);
-                Act e1[KT0];
-                encode3<Mode, LP>(p, h, e1);
+                    for (int k = 0; k < 3; ++k) p[k] = point_on_ray(o[n][k], d[n][k], zc[n]);
+                    Act e1[KT0];
+                    encode3<Mode, LP>(p, h, e1, w0[n]);
 #pragma unroll
-                for (int t = 0; t < KT0; ++t) enc[t][n] = e1[t];
-            }
+                    for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
+                    if constexpr (Net::kDino) {
+                        const DinoTaps tp = dino_taps(a.dino, p);
+                        Act dt[2];
+                        dino_tiles<Mode>(a.dino.features, tp, h, w1[n], dt);
+                        x[KT0][n] = dt[0];
+                        x[KT0 + 1][n] = dt[1];
+                    }
+                }
+            };
 
             float out4[NT][4];
-            Net::eval(pipe, bias, h, P.net.n_layers, enc, dirT, out4);
+            Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
 
             float v[4];
 #pragma unroll
@@ -243,41 +253,66 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
 
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         int64_t sid[NT];
-        Act enc[KT0][NT];
         Act dirT[1][NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int64_t r = tile * TILE + wave * (32 * NT) + 32 * n + c;
             sid[n] = r < P.n ? r : P.n - 1;
             if constexpr (Net::kNeedsDir) {
-                float p[3], dd[3];
+                float dd[3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { p[k] = P.pos[sid[n] * 3 + k]; dd[k] = P.dir[sid[n] * 3 + k]; }
-                Act e1[KT0], t1[pe_tiles(LD)];
-                encode3<Mode, LP>(p, h, e1);
+                for (int k = 0; k < 3; ++k) dd[k] = P.dir[sid[n] * 3 + k];
+                Act t1[pe_tiles(LD)];
                 encode3<Mode, LD>(dd, h, t1);
-#pragma unroll
-                for (int t = 0; t < KT0; ++t) enc[t][n] = e1[t];
                 dirT[0][n] = t1[0];
-            } else {
-                // gather the already-encoded features into operand order (feature_map.hpp)
-                const float* x = P.x_enc + sid[n] * PE;
-                f32x16 e[KT0];
-                static_for<16 * KT0>([&](auto u_) {
-                    constexpr int u = decltype(u_)::value;
-                    constexpr int i0 = pe_ref_index(LP, u, 0), i1 = pe_ref_index(LP, u, 1);
-                    float val = 0.0f;
-                    if constexpr (i0 >= 0 && i1 >= 0) val = x[h ? i1 : i0];
-                    else if constexpr (i0 >= 0) val = h ? 0.0f : x[i0];
-                    else if constexpr (i1 >= 0) val = h ? x[i1] : 0.0f;
-                    e[u / 16][u % 16] = val;
-                });
-#pragma unroll
-                for (int t = 0; t < KT0; ++t) enc[t][n] = Mode::template to_act<false>(e[t]);
             }
         }
+        auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if constexpr (Net::kNeedsDir) {
+                    float p[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[k] = P.pos[sid[n] * 3 + k];
+                    Act e1[KT0];
+                    encode3<Mode, LP>(p, h, e1, w0[n]);
+#pragma unroll
+                    for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
+                    if constexpr (Net::kDino) {
+                        // features handed over per sample (NeRFMLP.forward's third argument): channel 32t+8g+4h+q
+                        const float* f = P.dino + sid[n] * 64;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            f32x16 e;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = *(const f32x4*)(f + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) e[4 * g + q] = v[q] * w1[n];
+                            }
+                            x[KT0 + t][n] = Mode::template to_act<false>(e);
+                        }
+                    }
+                } else {
+                    // gather the already-encoded features into operand order (feature_map.hpp)
+                    const float* xin = P.x_enc + sid[n] * PE;
+                    f32x16 e[KT0];
+                    static_for<16 * KT0>([&](auto u_) {
+                        constexpr int u = decltype(u_)::value;
+                        constexpr int i0 = pe_ref_index(LP, u, 0), i1 = pe_ref_index(LP, u, 1);
+                        float val = 0.0f;
+                        if constexpr (i0 >= 0 && i1 >= 0) val = xin[h ? i1 : i0];
+                        else if constexpr (i0 >= 0) val = h ? 0.0f : xin[i0];
+                        else if constexpr (i1 >= 0) val = h ? xin[i1] : 0.0f;
+                        e[u / 16][u % 16] = val;
+                    });
+#pragma unroll
+                    for (int t = 0; t < KT0; ++t) x[t][n] = Mode::template to_act<false>(e[t]);
+                }
+            }
+        };
         float out4[NT][4];
-        Net::eval(pipe, bias, h, P.net.n_layers, enc, dirT, out4);
+        Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
         const int64_t own_raw = tile * TILE + wave * (32 * NT) + 32 * own + c;
         if (owner && own_raw < P.n) {
             float v[4];
@@ -380,7 +415,8 @@ int launch_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream
     if (a.n_rays <= 0) return NRF_OK;
     if (net.arch.net == NRF_NET_V1 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE(run_render, NetV1, 10, net, mode, a, s, err) }
     if (net.arch.net == NRF_NET_V2 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE(run_render, NetV2, 10, net, mode, a, s, err) }
-    err = "no fused renderer built for this (net, pos_freq)";
+    if (net.arch.net == NRF_NET_V3 && net.arch.pos_freq == 12) { NRF_DISPATCH_MODE(run_render, NetV3, 12, net, mode, a, s, err) }
+    err = "no fused renderer built for this (net, pos_freq): V1/V2 with pos_freq 10 (baseline.yaml) and V3 with pos_freq 12 (dino_nerf.yaml) are";
     return NRF_EUNSUPPORTED;
 }
 
@@ -400,9 +436,12 @@ int launch_forward(const DeviceNet& net, int mode, const float* pos, const float
     if (!check_net(net, mode, err)) return NRF_EINVAL;
     if (n <= 0) return NRF_OK;
     ForwardKArgs k{};
-    k.pos = pos; k.dir = dir; k.n = n; k.rgb = rgb; k.density = density;
-    (void)dino;
+    k.pos = pos; k.dir = dir; k.dino = dino; k.n = n; k.rgb = rgb; k.density = density;
     if (net.arch.net == NRF_NET_V2 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE(run_forward, NetV2, 10, net, mode, k, s, err) }
+    if (net.arch.net == NRF_NET_V3 && net.arch.pos_freq == 12) {
+        if (!dino) { err = "V3 forward needs per-sample dino features"; return NRF_EINVAL; }
+        NRF_DISPATCH_MODE(run_forward, NetV3, 12, net, mode, k, s, err)
+    }
     err = "no forward built for this (net, pos_freq)";
     return NRF_EUNSUPPORTED;
 }

@@ -20,8 +20,9 @@ __device__ __attribute__((noinline)) float precise_sin_or_cos(float arg, int wan
 // Positional encoding of one 3-vector into KT operand tiles, for lane half h
 // (feature_map.hpp: half 0 = sines + x,y; half 1 = cosines + z).
 // positional_encoding.py:27-33: sin/cos of x * 2^f, arguments exact (power-of-two scaling).
+// `scale` multiplies every feature (NeRFDINOFusion's attention weight, lora_dino.py:187); 1 elsewhere.
 template <class Mode, int L>
-__device__ __forceinline__ void encode3(const float p[3], int h, typename Mode::Act (&out)[pe_tiles(L)]) {
+__device__ __forceinline__ void encode3(const float p[3], int h, typename Mode::Act (&out)[pe_tiles(L)], float scale = 1.0f) {
     constexpr int KT = pe_tiles(L);
     f32x16 e[KT];
     float hi[3], lo[3];
@@ -52,7 +53,7 @@ __device__ __forceinline__ void encode3(const float p[3], int h, typename Mode::
         } else if constexpr (u == 3 * L + 1) {
             v = h ? 0.0f : p[1];
         }
-        e[t][r] = v;
+        e[t][r] = v * scale;
     });
 #pragma unroll
     for (int t = 0; t < KT; ++t) out[t] = Mode::template to_act<false>(e[t]);
@@ -69,11 +70,21 @@ struct NetV1 {
     static constexpr bool kNeedsDir = false;
     typedef typename Mode::Act Act;
 
-    template <class P>
+    static constexpr bool kDino = false;
+    // `inputs(w0, w1, x)` fills the first layer's operand tiles (the encoder lives with the caller: fused
+    // renderer = from the ray, staged forward = from memory); w0/w1 are only meaningful for NetV3
+    template <class P, class Inputs>
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
-                                                const Act (&enc)[KT0][NT], const Act (&)[1][NT], float (&out4)[NT][4]) {
+                                                Inputs&& inputs, const Act (&)[1][NT], float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
-        dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);
+        {
+            Act enc[KT0][NT];
+            float one[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) one[n] = 1.0f;
+            inputs(one, one, enc);
+            dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);
+        }
         int boff = 32 * HT;
         const int hidden = n_layers - 1;
         for (int p = 0; p < hidden / 2; ++p) {
@@ -102,14 +113,19 @@ struct NetV2 {
     static constexpr int KT0 = pe_tiles(LP);
     static constexpr int HT = 8;
     static constexpr bool kNeedsDir = true;
+    static constexpr bool kDino = false;
     typedef typename Mode::Act Act;
 
     // density_head, feature_head, colour layers; X = trunk output, Y = scratch of the same shape
     template <class P>
     __device__ static __forceinline__ void tail(P& pipe, const NRF_LDS float* bias, int h, const Act (&X)[HT][NT],
                                                 Act (&Y)[HT][NT], const Act (&dir)[1][NT], float (&out4)[NT][4]) {
-        f32x16 dens[NT];
-        dense_head<Mode, HT, NT>(pipe, bias, h, X, dens);
+        {   // keep only the density scalar alive across the colour branch, not its 16-register tile
+            f32x16 dens[NT];
+            dense_head<Mode, HT, NT>(pipe, bias, h, X, dens);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) out4[n][3] = dens[n][0];
+        }
         dense_act<Mode, HT, HT, NT, false>(pipe, bias + 32, h, X, Y);                     // feature_head: no activation
         Act in9[HT + 1][NT];
 #pragma unroll
@@ -126,15 +142,21 @@ struct NetV2 {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             out4[n][0] = rgb[n][0]; out4[n][1] = rgb[n][1]; out4[n][2] = rgb[n][2];
-            out4[n][3] = dens[n][0];
         }
     }
 
-    template <class P>
+    template <class P, class Inputs>
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
-                                                const Act (&enc)[KT0][NT], const Act (&dir)[1][NT], float (&out4)[NT][4]) {
+                                                Inputs&& inputs, const Act (&dir)[1][NT], float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
-        dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);
+        {
+            Act enc[KT0][NT];
+            float one[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) one[n] = 1.0f;
+            inputs(one, one, enc);
+            dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);
+        }
         int boff = 32 * HT;
         const int hidden = n_layers - 1;
         for (int p = 0; p < hidden / 2; ++p) {
@@ -149,5 +171,129 @@ struct NetV2 {
         }
     }
 };
+
+// ---------------------------------------------------------------------------
+// V3: nerf_mlp.py:134-158 NeRFWithDINO = NeRFDINOFusion (lora_dino.py:171-193) -> DensityMLP -> ColorMLP
+//   fused = fusion(cat[pe, dino]); w = softmax(attention(fused));
+//   x     = output_proj(fusion(cat[pe*w0, dino*w1]))        (the same `fusion` weights, streamed twice)
+// The first-layer operand tiles are rebuilt for the second pass (re-encode + re-fetch, scaled) instead of
+// being kept in registers across the first pass: 40 VGPRs cheaper than holding them.
+// ---------------------------------------------------------------------------
+template <class Mode, int NT, int LP>
+struct NetV3 {
+    static constexpr int PT = pe_tiles(LP);
+    static constexpr int DT = 2;                   // dino_dim 64
+    static constexpr int KT0 = PT + DT;
+    static constexpr int HT = 8;
+    static constexpr bool kNeedsDir = true;
+    static constexpr bool kDino = true;
+    typedef typename Mode::Act Act;
+
+    template <class P, class Inputs>
+    __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
+                                                Inputs&& inputs, const Act (&dir)[1][NT], float (&out4)[NT][4]) {
+        Act A[HT][NT], B[HT][NT];
+        float w0[NT], w1[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) w0[n] = w1[n] = 1.0f;
+        int boff = 0;
+        {
+            Act x[KT0][NT];
+            inputs(w0, w1, x);
+            dense_act<Mode, KT0, HT, NT, true>(pipe, bias + boff, h, x, A); boff += 32 * HT;
+        }
+        dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
+        {   // attention: Linear(256->64)+ReLU, Linear(64->2), softmax over the pair (lora_dino.py:162-167,184)
+            Act a0[HT / 4][NT];
+            dense_act<Mode, HT, HT / 4, NT, true>(pipe, bias + boff, h, B, a0); boff += 8 * HT;
+            f32x16 lg[NT];
+            dense_head<Mode, HT / 4, NT>(pipe, bias + boff, h, a0, lg); boff += 32;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float d = lg[n][1] - lg[n][0];
+                w0[n] = 1.0f / (1.0f + (Mode::FAST_EXP ? __expf(d) : expf(d)));
+                w1[n] = 1.0f - w0[n];
+            }
+        }
+        {
+            Act x[KT0][NT];
+            inputs(w0, w1, x);
+            dense_act<Mode, KT0, HT, NT, true>(pipe, bias + boff, h, x, A); boff += 32 * HT;
+        }
+        dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
+        dense_act<Mode, HT, HT, NT, false>(pipe, bias + boff, h, B, A); boff += 32 * HT;       // output_proj: no activation
+        for (int p = 0; p < n_layers / 2; ++p) {
+            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
+            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, B, A); boff += 32 * HT;
+        }
+        if (n_layers & 1) {
+            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
+            NetV2<Mode, NT, LP>::tail(pipe, bias + boff, h, B, A, dir, out4);
+        } else {
+            NetV2<Mode, NT, LP>::tail(pipe, bias + boff, h, A, B, dir, out4);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------
+// DINO side channel (ray_utils.py:176-210 + dino_feature_model.py:114-148): project a sample into the source
+// view, bilinear taps of the (1,Hp,Wp,C) map with zeros padding, align_corners=False.
+// ---------------------------------------------------------------------------
+struct DinoTaps {
+    int off[4];      // element offset of the tap's channel 0, or -1 outside the map
+    float w[4];
+};
+
+template <class DinoT>
+__device__ __forceinline__ DinoTaps dino_taps(const DinoT& d, const float p[3]) {
+    float pc[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        pc[i] = d.inv_pose[4 * i + 0] * p[0] + d.inv_pose[4 * i + 1] * p[1] + d.inv_pose[4 * i + 2] * p[2] + d.inv_pose[4 * i + 3];
+    const float zi = pc[2] + 1e-8f;
+    const float xn = (pc[0] / zi * d.focal + (float)d.W / 2.0f) / (float)d.W * 2.0f - 1.0f;
+    const float yn = (pc[1] / zi * d.focal + (float)d.H / 2.0f) / (float)d.H * 2.0f - 1.0f;
+    const float gx = ((xn + 1.0f) * (float)d.Wp - 1.0f) * 0.5f;
+    const float gy = ((yn + 1.0f) * (float)d.Hp - 1.0f) * 0.5f;
+    const float x0 = floorf(gx), y0 = floorf(gy);
+    DinoTaps t;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const float xi = x0 + dx, yi = y0 + dy;
+            const float wx = dx ? gx - x0 : x0 + 1.0f - gx;
+            const float wy = dy ? gy - y0 : y0 + 1.0f - gy;
+            const bool ok = xi >= 0.0f && xi <= (float)(d.Wp - 1) && yi >= 0.0f && yi <= (float)(d.Hp - 1);
+            t.off[2 * dy + dx] = ok ? ((int)yi * d.Wp + (int)xi) * d.C : -1;
+            t.w[2 * dy + dx] = ok ? wx * wy : 0.0f;
+        }
+    return t;
+}
+
+// the 64 fetched channels as two operand tiles for lane half h: register 4g+e of tile t holds channel 32t+8g+4h+e
+template <class Mode>
+__device__ __forceinline__ void dino_tiles(const float* __restrict__ feat, const DinoTaps& tp, int h, float scale,
+                                           typename Mode::Act (&out)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        f32x16 e;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int ch = 32 * t + 8 * g + 4 * h;
+            f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (tp.off[k] >= 0) {
+                    const f32x4 v = *(const f32x4*)(feat + tp.off[k] + ch);
+                    acc += v * tp.w[k];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[4 * g + q] = acc[q] * scale;
+        }
+        out[t] = Mode::template to_act<false>(e);
+    }
+}
 
 }  // namespace nrf

@@ -145,8 +145,54 @@ bool make_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, NetPlan& p
         for (int rep = 0; rep < 2; ++rep)
             for (int c = 0; c < 3; ++c) C4.row[4 * rep + c] = {n + 4, c};
         add(std::move(C4));
+    } else if (a.net == NRF_NET_V3) {
+        // lora_dino.py:171-193 + nerf_mlp.py:144-158.  Stream order = the order nets.hpp:NetV3 walks:
+        // fusion.0, fusion.2, attention.0, attention.2, fusion.0, fusion.2 (the SAME weights, second pass),
+        // output_proj, trunk, density_head, feature_head, colour layers.
+        if (a.dir_freq < 1 || 3 * a.dir_freq + 2 > 16) { err = "dir_freq must be in 1..4 (one operand tile)"; return false; }
+        if (a.dino_dim != 64) { err = "only dino_dim=64 is built (two operand tiles)"; return false; }
+        const int n = a.n_layers, de = pe_dim(a.dir_freq), DT = a.dino_dim / 32;
+        if (!check(lin, 0, H, pe + a.dino_dim, "dino_fusion.fusion.0", err) || !check(lin, 1, H, H, "dino_fusion.fusion.2", err) ||
+            !check(lin, 2, H / 4, H, "dino_fusion.attention.0", err) || !check(lin, 3, 2, H / 4, "dino_fusion.attention.2", err) ||
+            !check(lin, 4, H, H, "dino_fusion.output_proj", err))
+            return false;
+        const int b = 5;
+        for (int i = 0; i < n; ++i)
+            if (!check(lin, b + i, H, H, "density_layers.N", err)) return false;
+        if (!check(lin, b + n, 1, H, "density_head", err) || !check(lin, b + n + 1, H, H, "feature_head", err) ||
+            !check(lin, b + n + 2, H / 2, H + de, "color_layers.0", err) || !check(lin, b + n + 3, H / 4, H / 2, "color_layers.2", err) ||
+            !check(lin, b + n + 4, 3, H / 4, "color_layers.4", err))
+            return false;
+        auto fusion0 = [&]() {
+            LayerPlan L; L.KT = peT + DT; L.MT = HT; L.col.assign(32 * (peT + DT), -1);
+            pe_cols(L.col, 0, a.pos_freq, 0);
+            for (int k = 0; k < a.dino_dim; ++k) L.col[32 * peT + k] = pe + k;          // channel k of the fetched feature
+            L.row = rows_of(0, H, HT);
+            return L;
+        };
+        auto square = [&](int li) { LayerPlan L; L.KT = HT; L.MT = HT; L.col = identity_cols(H); L.row = rows_of(li, H, HT); return L; };
+        add(fusion0()); add(square(1));
+        LayerPlan A0; A0.KT = HT; A0.MT = H / 128; A0.col = identity_cols(H); A0.row = rows_of(2, H / 4, H / 128); add(std::move(A0));
+        LayerPlan A2; A2.KT = H / 128; A2.MT = 1; A2.col = identity_cols(H / 4); A2.row.assign(32, {-1, 0});
+        for (int rep = 0; rep < 2; ++rep) { A2.row[4 * rep + 0] = {3, 0}; A2.row[4 * rep + 1] = {3, 1}; }   // logits in regs 0,1 of both lane halves
+        add(std::move(A2));
+        add(fusion0()); add(square(1));
+        add(square(4));
+        for (int i = 0; i < n; ++i) add(square(b + i));
+        LayerPlan Dh; Dh.KT = HT; Dh.MT = 1; Dh.col = identity_cols(H); Dh.row.assign(32, {-1, 0});
+        Dh.row[0] = {b + n, 0}; Dh.row[4] = {b + n, 0}; add(std::move(Dh));
+        add(square(b + n + 1));
+        LayerPlan C0; C0.KT = HT + 1; C0.MT = H / 64; C0.col.assign(32 * (HT + 1), -1);
+        for (int k = 0; k < H; ++k) C0.col[k] = k;
+        pe_cols(C0.col, H, a.dir_freq, H);
+        C0.row = rows_of(b + n + 2, H / 2, H / 64); add(std::move(C0));
+        LayerPlan C2; C2.KT = H / 64; C2.MT = H / 128; C2.col = identity_cols(H / 2); C2.row = rows_of(b + n + 3, H / 4, H / 128); add(std::move(C2));
+        LayerPlan C4; C4.KT = H / 128; C4.MT = 1; C4.col = identity_cols(H / 4); C4.row.assign(32, {-1, 0});
+        for (int rep = 0; rep < 2; ++rep)
+            for (int c = 0; c < 3; ++c) C4.row[4 * rep + c] = {b + n + 4, c};
+        add(std::move(C4));
     } else {
-        err = "network family not built into this library yet";
+        err = "unknown network family";
         return false;
     }
 
@@ -155,6 +201,7 @@ bool make_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, NetPlan& p
     plan.n_bias = off;
     int64_t mac = 0;
     for (const auto& l : lin) mac += (int64_t)l.out_f * l.in_f;
+    if (a.net == NRF_NET_V3) mac += (int64_t)lin[0].out_f * lin[0].in_f + (int64_t)lin[1].out_f * lin[1].in_f;   // fusion runs twice
     plan.flops_per_sample = 2 * mac;
     return true;
 }

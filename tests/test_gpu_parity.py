@@ -50,6 +50,17 @@ def model_v2(N, scene="fog", mode="f32", seed=1):
     return m.cuda().eval(), p
 
 
+def model_v3(N, scene="fog", mode="f32", seed=2):
+    m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=mode)
+    p = O.make_weights("v3", seed, scene)
+    m.load_state_dict(p, strict=False)
+    return m.cuda().eval(), p
+
+
+def dino_map():
+    return torch.from_numpy(O.uniform01(7, 28 * 28 * 64).reshape(1, 28, 28, 64) * 2 - 1)
+
+
 # ------------------------------------------------------------------ a1 rays (bit exact)
 def test_get_rays_bit_exact(N, golden):
     g = golden("rays")
@@ -207,6 +218,39 @@ def test_mlp_v2_golden(N, golden):
         with torch.no_grad():
             rgb, dens = m(T(g["pos"]), T(g["dirs"]), None)
         assert maxdiff(rgb, g["rgb"]) <= tol and maxdiff(dens, g["density"]) <= tol
+
+
+def test_mlp_v3_golden(N, golden):
+    """NeRFWithDINO (nerf_mlp.py:134-158) incl. the twice-run fusion block and its softmax gate."""
+    g = golden("mlp_v3")
+    m, _ = model_v3(N, "fog", "f32")
+    with torch.no_grad():
+        rgb, dens = m(T(g["pos"]), T(g["dirs"]), T(g["dino"]))
+    assert maxdiff(rgb, g["rgb"]) <= 2e-5 and maxdiff(dens, g["density"]) <= 2e-5 * max(1.0, float(g["density"].max()))
+    for mode, tol in (("f16", 1e-2), ("bf16", 1e-1)):
+        m.mma_mode = mode
+        with torch.no_grad():
+            rgb, dens = m(T(g["pos"]), T(g["dirs"]), T(g["dino"]))
+        assert maxdiff(rgb, g["rgb"]) <= tol
+
+
+def test_render_v3_end_to_end_golden(N, golden):
+    """Config C4 path: project each sample into the source view, bilinear fetch of the feature map, fusion, trunk,
+    colour, composite -- one kernel -- against the reference's outputs (train.py:203-242)."""
+    g = golden("end_to_end")
+    H, W, S = int(g["H"]), int(g["W"]), int(g["S"])
+    ro, rd = N.get_rays(H, W, float(g["focal"]), T(g["c2w"]))
+    m, _ = model_v3(N, "fog", "f32")
+    dino = dict(features=dino_map(), pose=T(g["c2w"]), focal=float(g["focal"]), H=H, W=W)
+    for tag, tr in (("plain", None), ("jit", T(g["t_rand"]))):
+        out = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=tr, dino=dino)
+        assert maxdiff(out["rgb"], g[f"v3_fog_{tag}_rgb"]) <= TOL
+        assert maxdiff(out["depth"], g[f"v3_fog_{tag}_depth"]) <= TOL
+        assert maxdiff(out["weights"], g[f"v3_fog_{tag}_w"]) <= TOL
+    out16 = N.render_rays(m, ro, rd, 2.0, 6.0, S, dino=dino, mma_mode="bf16")
+    assert O.psnr(out16["rgb"].cpu(), T(g["v3_fog_plain_rgb"])) > 25
+    with pytest.raises(ValueError):
+        N.render_rays(m, ro, rd, 2.0, 6.0, S)                    # a use_dino model without its side channel
 
 
 def test_model_update_repacks(N, golden):

@@ -43,7 +43,7 @@ def _pack(L, variant, p, mode, **arch_kw):
         keep += [w, b]
         arr[i] = L.nrf_linear(w.ctypes.data_as(L.c_float_p), b.ctypes.data_as(L.c_float_p), w.shape[0], w.shape[1])
     net = {"v1": 1, "v2": 2, "v3": 3}[variant]
-    arch = L.nrf_arch(net, arch_kw.get("pos_freq", 10), 4, 256, arch_kw.get("n_layers", 8), 0)
+    arch = L.nrf_arch(net, arch_kw.get("pos_freq", 12 if variant == "v3" else 10), 4, 256, arch_kw.get("n_layers", 8), 64 if variant == "v3" else 0)
     nb, ns = C.c_int64(), C.c_int64()
     L.check(L.lib().nrf_debug_pack(C.byref(arch), arr, len(names), L.MMA_MODES[mode], None, 0, C.byref(ns), None, 0, C.byref(nb)))
     raw = (C.c_uint8 * ns.value)()
@@ -127,6 +127,55 @@ def test_v2_stream_replay_matches_oracle(L, mode, tol):
     assert np.abs(got_rgb - ref_rgb.numpy()).max() < tol
     assert np.abs(np.maximum(dens[0, :32, 0], 0) - ref_dens.numpy()[:, 0]).max() < tol * max(1.0, float(ref_dens.max()))
     assert np.array_equal(dens[0, :32, 0], dens[0, 32:, 0])               # both lane halves see the density
+
+
+def test_v3_stream_replay_matches_oracle(L):
+    """NeRFWithDINO: the fusion block's weights appear twice in the stream; the softmax gate rescales the inputs."""
+    mode, tol = "f32", 5e-5
+    p = O.make_weights("v3", 2)
+    raw, bias = _pack(L, "v3", p, mode)
+    st = E.Stream(raw, mode)
+    x = ((O.uniform01(6, 96).reshape(32, 3) * 2 - 1) * 3).astype(np.float32)
+    d = (O.uniform01(7, 96).reshape(32, 3) * 2 - 1).astype(np.float32)
+    dino = (O.uniform01(8, 32 * 64).reshape(32, 64) * 2 - 1).astype(np.float32)
+    dirt = _encode_tiles(d, 4)
+
+    def inputs(w0, w1):
+        pe = _encode_tiles(x, 12)                                            # 3 tiles
+        pe_m = E.matrix_from_tiles(pe) * w0[None, :]
+        dn = dino.T * w1[None, :]                                            # (64 channels, 32 samples): K index = channel
+        return E.tiles_from_matrix(np.concatenate([pe_m, dn], 0).astype(np.float32))
+
+    off = [0]
+
+    def layer(act, MT, relu=True):
+        acc = E.dense(st, bias[off[0]:off[0] + 32 * MT], act, MT, mode)
+        off[0] += 32 * MT
+        return np.maximum(acc, 0) if relu else acc
+
+    one = np.ones(32, np.float32)
+    f = layer(layer(inputs(one, one), 8), 8)
+    a0 = layer(f, 2)
+    lg = layer(a0, 1, relu=False)
+    l0, l1 = lg[0, :32, 0], lg[0, :32, 1]
+    assert np.array_equal(l0, lg[0, 32:, 0]) and np.array_equal(l1, lg[0, 32:, 1])
+    w0 = 1 / (1 + np.exp(l1 - l0)); w1 = 1 - w0
+    f2 = layer(layer(inputs(w0.astype(np.float32), w1.astype(np.float32)), 8), 8)
+    hcur = layer(f2, 8, relu=False)                                          # output_proj
+    fused_ref = O.dino_fusion(p, "dino_fusion.", O.positional_encoding(torch.from_numpy(x), 12), torch.from_numpy(dino)).numpy()
+    assert np.abs(E.matrix_from_tiles(hcur).T - fused_ref).max() < tol * max(1.0, np.abs(fused_ref).max())
+    for _ in range(8):
+        hcur = layer(hcur, 8)
+    dens = layer(hcur, 1, relu=False)
+    feat = layer(hcur, 8, relu=False)
+    c0 = layer(np.concatenate([feat, dirt], 0), 4)
+    c1 = layer(c0, 2)
+    rgb = layer(c1, 1, relu=False)
+    assert off[0] == bias.shape[0] and (st.pos + 15) // 16 == st.frags.shape[0] // 16
+    ref_rgb, ref_dens = O.mlp_v3(p, torch.from_numpy(x), torch.from_numpy(d), torch.from_numpy(dino))
+    got_rgb = 1 / (1 + np.exp(-np.stack([rgb[0, :32, k] for k in range(3)], -1)))
+    assert np.abs(got_rgb - ref_rgb.numpy()).max() < 1e-4
+    assert np.abs(np.maximum(dens[0, :32, 0], 0) - ref_dens.numpy()[:, 0]).max() < 1e-4 * max(1.0, float(ref_dens.max()))
 
 
 def test_model_create_validates_shapes(L):

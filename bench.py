@@ -147,6 +147,16 @@ def main():
     value = samples_per_step * args.steps / dt / 1e6
     achieved = samples_per_launch * flops_per_sample / (kernel_ms * 1e-3) / 1e12
 
+    # HBM bytes per launch come from PMC counters, which bench.py cannot collect itself: they are read from the
+    # committed rocprofv3 summary of this very workload (profiles/r01_pmc_summary.json), else reported as null
+    traffic = None
+    try:
+        if (args.net, args.mode, H, W, S, world) == ("v1", "bf16", 800, 800, 64, 1):
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                traffic = json.load(f)["derived"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        traffic = None
+
     out = {
         "metric": "M ray-samples/sec (sample+MLP+composite) at 800^2x64",
         "value": round(value, 2), "unit": "M ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,7 +167,8 @@ def main():
                    "rays_per_gpu_per_step": job.rays_per_launch, "samples_per_ray": S, "ert_eps": args.ert,
                    "flops_per_sample": flops_per_sample, "parallelism": f"pixel-tile x{world}"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.mode], "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": None,
+                     "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_summary.json (FETCH_SIZE*2 + WRITE_SIZE, bytes per launch)" if traffic else None,
                      "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ev)},
     }
 

@@ -92,6 +92,8 @@ typedef struct nrf_render_opts {
                                 (scalar torch.linspace formula).  torch's CPU linspace is vectorised and its last ulp
                                 depends on the host: a caller that must match the reference bit for bit passes the
                                 ladder the reference computes (ray_utils.py:58-66) */
+    const float* z_in;       /* device (R,S) explicit, ascending per-ray depths (e.g. the sorted union of the coarse and the
+                                importance samples, ray_utils.py:136-139): overrides near/far/perturb/lindisp sampling */
     uint64_t rng_seed;
     float    ert_eps;        /* early ray termination: stop a wave once every live ray has T < eps; 0 = off (reference behaviour) */
     int32_t  white_bkgd;     /* nerf_mlp.py:209-212                                                   */

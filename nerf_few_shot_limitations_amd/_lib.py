@@ -43,7 +43,7 @@ class nrf_dino(C.Structure):
 
 class nrf_render_opts(C.Structure):
     _fields_ = [("near", C.c_float), ("far", C.c_float), ("n_samples", C.c_int32), ("lindisp", C.c_int32),
-                ("perturb", C.c_int32), ("t_rand", C.c_void_p), ("z_ladder", C.c_void_p), ("rng_seed", C.c_uint64), ("ert_eps", C.c_float),
+                ("perturb", C.c_int32), ("t_rand", C.c_void_p), ("z_ladder", C.c_void_p), ("z_in", C.c_void_p), ("rng_seed", C.c_uint64), ("ert_eps", C.c_float),
                 ("white_bkgd", C.c_int32), ("mma_mode", C.c_int32), ("dino", C.POINTER(nrf_dino))]
 
 

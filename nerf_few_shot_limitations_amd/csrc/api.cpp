@@ -127,7 +127,7 @@ int check_opts(const nrf_render_opts* o) {
 
 void fill_common(nrf::RenderArgs& a, const nrf_render_opts* o, float* rgb, float* depth, float* weights, float* z_vals) {
     a.near = o->near; a.far = o->far; a.n_samples = o->n_samples; a.lindisp = o->lindisp; a.perturb = o->perturb;
-    a.t_rand = o->perturb ? o->t_rand : nullptr; a.z_ladder = o->z_ladder; a.seed = o->rng_seed;
+    a.t_rand = o->perturb ? o->t_rand : nullptr; a.z_ladder = o->z_ladder; a.z_in = o->z_in; a.seed = o->rng_seed;
     a.ert_eps = o->ert_eps; a.white_bkgd = o->white_bkgd;
     a.rgb = rgb; a.depth = depth; a.weights = weights; a.z_vals = z_vals;
 }
@@ -247,7 +247,7 @@ int nrf_render_cameras_tiles(const nrf_model* m, int H, int W, float focal, cons
     if (!rgb || !depth) return fail(NRF_EINVAL, "nrf_render_cameras_tiles: null output pointer");
     const int rc = check_opts(opts);
     if (rc != NRF_OK) return rc;
-    if (opts->t_rand) return fail(NRF_EINVAL, "tile rendering draws its jitter from the counter RNG (t_rand must be NULL)");
+    if (opts->t_rand || opts->z_in) return fail(NRF_EINVAL, "tile rendering takes no per-ray inputs (t_rand and z_in must be NULL)");
     nrf::RenderArgs a{};
     a.camera_mode = 1; a.n_cams = n_cams;
     for (int c = 0; c < n_cams; ++c) a.cams[c] = make_camera(H, W, focal, c2w + 12 * c);

@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
         }
 
         auto z_ray = [&](int64_t ray, int s) -> float {
+            if (a.z_in) return a.z_in[ray * S + s];
             if (!a.perturb) return ladder_z(lad, s);
             float u;
             if (a.t_rand) {

@@ -49,6 +49,7 @@ struct RenderArgs {
     int n_samples, lindisp, perturb;
     const float* t_rand;
     const float* z_ladder;
+    const float* z_in;
     uint64_t seed;
     // compositing
     float ert_eps;

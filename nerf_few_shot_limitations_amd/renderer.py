@@ -34,12 +34,13 @@ def make_dino(features, pose, focal, H, W):
     return d, fm
 
 
-def _opts(near, far, n_samples, perturb, t_rand, seed, lindisp, ert_eps, white_bkgd, mma_mode, dino, device):
+def _opts(near, far, n_samples, perturb, t_rand, seed, lindisp, ert_eps, white_bkgd, mma_mode, dino, device, z_in=None):
     o = L.nrf_render_opts()
     o.near, o.far, o.n_samples, o.lindisp = float(near), float(far), int(n_samples), int(bool(lindisp))
     o.perturb = int(bool(perturb) or t_rand is not None)
     o.t_rand = t_rand.data_ptr() if t_rand is not None else None
     o.z_ladder = L.z_ladder(near, far, n_samples, lindisp, device).data_ptr()     # cached per (near, far, S, device)
+    o.z_in = z_in.data_ptr() if z_in is not None else None
     o.rng_seed = int(seed)
     o.ert_eps, o.white_bkgd, o.mma_mode = float(ert_eps), int(bool(white_bkgd)), L.MMA_MODES[mma_mode]
     o.dino = C.pointer(dino) if dino is not None else None
@@ -47,20 +48,22 @@ def _opts(near, far, n_samples, perturb, t_rand, seed, lindisp, ert_eps, white_b
 
 
 def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb=False, t_rand=None, seed=0, lindisp=False,
-                ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, return_weights=True, return_z=False):
+                ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, return_weights=True, return_z=False,
+                z_in=None):
     """Render explicit rays (R,3)/(H,W,3) -> {'rgb' (R,3), 'depth' (R,), 'weights' (R,S)[, 'z_vals' (R,S)]}."""
     L.require_gpu()
     o = L.dev_f32(rays_o).reshape(-1, 3)
     d = L.dev_f32(rays_d, o.device).reshape(-1, 3)
     R, S = o.shape[0], int(N_samples)
     tr = L.dev_f32(t_rand, o.device).reshape(R, S) if t_rand is not None else None
+    zin = L.dev_f32(z_in, o.device).reshape(R, S) if z_in is not None else None
     keep = None
     dn = None
     if model.net == L.NRF_NET_V3:
         if dino is None:
             raise ValueError("a use_dino model needs dino=dict(features=, pose=, focal=, H=, W=)")
         dn, keep = make_dino(**dino)
-    opts = _opts(near, far, S, perturb, tr, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn, o.device)
+    opts = _opts(near, far, S, perturb, tr, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn, o.device, zin)
     h = model.handle(o.device)
     with torch.cuda.device(o.device):
         rgb = torch.empty((R, 3), dtype=torch.float32, device=o.device)
@@ -105,6 +108,24 @@ def render_camera(model: NeRFMLP, H, W, focal, c2w, near, far, N_samples=64, ray
                                           L.ptr(rgb), L.ptr(depth), None, None, L.stream_ptr()))
     del keep
     return rgb, depth
+
+
+def render_hierarchical(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=128, N_importance=64, perturb=False, u=None, **kw):
+    """Coarse pass -> inverse-cdf resampling of its weights -> fine pass on the sorted union of S+Ni depths
+    (BASELINE.json config 3: 128 coarse + 64 fine).  Mirrors the intent of ray_utils.py:86-143, which the
+    reference never calls and which raises on every input: parity of the resampling step is
+    unpinned, the two render passes are the same kernel as `render_rays`.
+    Returns the fine pass' dict plus 'coarse' (the coarse pass' dict) and 'z_vals' (R, S+Ni)."""
+    from .ray_sampler import sample_pdf
+    coarse = render_rays(model, rays_o, rays_d, near, far, N_samples, perturb=perturb, return_weights=True, return_z=True, **kw)
+    if u is None and perturb:
+        u = torch.rand((coarse["weights"].shape[0], int(N_importance)), device=coarse["weights"].device)
+    _, union = sample_pdf(coarse["z_vals"], coarse["weights"], N_importance, u=u)
+    kw.pop("t_rand", None)
+    fine = render_rays(model, rays_o, rays_d, near, far, N_samples + int(N_importance), z_in=union, return_weights=True, **kw)
+    fine["coarse"] = coarse
+    fine["z_vals"] = union
+    return fine
 
 
 class NeRFRenderer:

@@ -334,7 +334,7 @@ def volume_render_radiance(rgb_sigma, z_vals, rays_d):
 # --------------------------------------------------------------------------
 
 def render_rays(p, variant, rays_o, rays_d, near, far, n_samples, t_rand=None,
-                white_bkgd=False, pos_freq=None, dir_freq=4, dino=None, chunk=2048):
+                white_bkgd=False, pos_freq=None, dir_freq=4, dino=None, chunk=2048, z_in=None):
     """src/training/train.py:188-242 with D1-D4 repaired.
 
     variant 'v1': PE(10) -> nerf_model.NeRFMLP -> compositor (train_minimal.py:97-102 wiring);
@@ -354,6 +354,9 @@ def render_rays(p, variant, rays_o, rays_d, near, far, n_samples, t_rand=None,
             o, d = rays_o[b:b + chunk], rays_d[b:b + chunk]
             tr = None if t_rand is None else torch.as_tensor(t_rand, dtype=torch.float32)[b:b + chunk]
             pts, z = sample_points_along_rays(o, d, near, far, n_samples, tr)
+            if z_in is not None:                      # explicit depths (fine pass of hierarchical sampling, ray_utils.py:139)
+                z = torch.as_tensor(z_in, dtype=torch.float32)[b:b + chunk]
+                pts = o[..., None, :] + d[..., None, :] * z[..., :, None]
             n = o.shape[0]
             pf = pts.reshape(-1, 3)
             df = d[:, None, :].expand(-1, n_samples, -1).reshape(-1, 3)

@@ -434,6 +434,29 @@ def test_sample_pdf_vs_oracle(N):
     assert torch.all(union[:, 1:] >= union[:, :-1])
 
 
+def test_hierarchical_render_c3(N):
+    """BASELINE.json config 3 shape (coarse + importance samples, sorted union, fine pass) at a size the oracle
+    finishes in seconds.  The resampling step's parity is unpinned (the reference function raises); the fine pass is
+    checked against the oracle ON THE SAME union depths, the union against the oracle's own resampling."""
+    H, W = 24, 20
+    S, Ni = 32, 16
+    c2w = T(O.LEGO_LIKE_C2W)
+    m, p = model_v1(N, "solid", "f32")
+    ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
+    out = N.render_hierarchical(m, ro, rd, 2.0, 6.0, S, Ni)
+    assert out["z_vals"].shape == (H * W, S + Ni) and out["weights"].shape == (H * W, S + Ni)
+    assert torch.all(out["z_vals"][:, 1:] >= out["z_vals"][:, :-1])
+    oro, ord_ = O.get_rays(H, W, O.focal_for(W), c2w)
+    coarse = O.render_rays(p, "v1", oro, ord_, 2.0, 6.0, S)
+    assert maxdiff(out["coarse"]["rgb"], coarse["rgb"]) <= TOL and maxdiff(out["coarse"]["weights"], coarse["weights"]) <= TOL
+    _, ounion = O.sample_pdf(coarse["z_vals"], coarse["weights"], Ni)
+    dz = (out["z_vals"].cpu() - ounion).abs()                           # resampling: parity unpinned, same intent; where a cdf
+    assert float(dz.max()) <= 2e-2 and float(dz.median()) <= 1e-5     # bin is nearly empty the inverse is ill-conditioned
+    fine = O.render_rays(p, "v1", oro, ord_, 2.0, 6.0, S + Ni, z_in=out["z_vals"].cpu())
+    assert maxdiff(out["rgb"], fine["rgb"]) <= TOL and maxdiff(out["depth"], fine["depth"]) <= TOL
+    assert maxdiff(out["weights"], fine["weights"]) <= TOL
+
+
 # ------------------------------------------------------------------ a8 projection + fetch
 def test_project_fetch_golden(N, golden):
     import ctypes as C

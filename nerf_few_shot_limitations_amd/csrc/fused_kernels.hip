@@ -38,7 +38,7 @@ struct ForwardKArgs {
     const float* x_enc;      // V1: (P, pe_dim)
     const float* pos;        // V2/V3: (P,3)
     const float* dir;        // V2/V3: (P,3)
-    const float* dino;       // V3: (P,64)
+    const float* dino;       // V3: (P,dino_dim)
     int64_t n;
     float* out4;             // V1: (P,4)
     float* rgb;              // V2/V3: (P,3)
@@ -170,11 +170,12 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 #pragma unroll
                     for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                     if constexpr (Net::kDino) {
+                        constexpr int DT = Net::KT0 - KT0;
                         const DinoTaps tp = dino_taps(a.dino, p);
-                        Act dt[2];
-                        dino_tiles<Mode>(a.dino.features, tp, h, w1[n], dt);
-                        x[KT0][n] = dt[0];
-                        x[KT0 + 1][n] = dt[1];
+                        Act dt[DT];
+                        dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
+#pragma unroll
+                        for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
                     }
                 }
             };
@@ -281,9 +282,10 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
                     for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                     if constexpr (Net::kDino) {
                         // features handed over per sample (NeRFMLP.forward's third argument): channel 32t+8g+4h+q
-                        const float* f = P.dino + sid[n] * 64;
+                        constexpr int DT = Net::KT0 - KT0;
+                        const float* f = P.dino + sid[n] * (32 * DT);
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
+                        for (int t = 0; t < DT; ++t) {
                             f32x16 e;
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
@@ -411,13 +413,25 @@ static bool wide_waves() {
         default: return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                         \
     }
 
+// V2 / V3: one geometry per mode (8 waves x 32 samples for the 16-bit modes, 4 x 32 for fp32)
+#define NRF_DISPATCH_MODE1(FN, NETT, LP, ...)                                                               \
+    switch (mode) {                                                                                         \
+        case NRF_MMA_BF16: return FN<NETT(ModeBF16), ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);                   \
+        case NRF_MMA_F16:  return FN<NETT(ModeF16), ModeF16, 1, 8, LP, 4>(__VA_ARGS__);                     \
+        default:           return FN<NETT(ModeF32), ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                     \
+    }
+#define NRF_NET_V2_10(M) NetV2<M, 1, 10>
+#define NRF_NET_V3_12_64(M) NetV3<M, 1, 12, 2>
+#define NRF_NET_V3_12_128(M) NetV3<M, 1, 12, 4>
+
 int launch_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
     if (!check_net(net, mode, err)) return NRF_EINVAL;
     if (a.n_rays <= 0) return NRF_OK;
     if (net.arch.net == NRF_NET_V1 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE(run_render, NetV1, 10, net, mode, a, s, err) }
-    if (net.arch.net == NRF_NET_V2 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE(run_render, NetV2, 10, net, mode, a, s, err) }
-    if (net.arch.net == NRF_NET_V3 && net.arch.pos_freq == 12) { NRF_DISPATCH_MODE(run_render, NetV3, 12, net, mode, a, s, err) }
-    err = "no fused renderer built for this (net, pos_freq): V1/V2 with pos_freq 10 (baseline.yaml) and V3 with pos_freq 12 (dino_nerf.yaml) are";
+    if (net.arch.net == NRF_NET_V2 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE1(run_render, NRF_NET_V2_10, 10, net, mode, a, s, err) }
+    if (net.arch.net == NRF_NET_V3 && net.arch.pos_freq == 12 && net.arch.dino_dim == 64) { NRF_DISPATCH_MODE1(run_render, NRF_NET_V3_12_64, 12, net, mode, a, s, err) }
+    if (net.arch.net == NRF_NET_V3 && net.arch.pos_freq == 12 && net.arch.dino_dim == 128) { NRF_DISPATCH_MODE1(run_render, NRF_NET_V3_12_128, 12, net, mode, a, s, err) }
+    err = "no fused renderer built for this (net, pos_freq): V1/V2 with pos_freq 10 (baseline.yaml) and V3 with pos_freq 12 and dino_dim 64/128 (dino_nerf.yaml, lora.yaml, multiscale.yaml) are";
     return NRF_EUNSUPPORTED;
 }
 
@@ -438,10 +452,11 @@ int launch_forward(const DeviceNet& net, int mode, const float* pos, const float
     if (n <= 0) return NRF_OK;
     ForwardKArgs k{};
     k.pos = pos; k.dir = dir; k.dino = dino; k.n = n; k.rgb = rgb; k.density = density;
-    if (net.arch.net == NRF_NET_V2 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE(run_forward, NetV2, 10, net, mode, k, s, err) }
+    if (net.arch.net == NRF_NET_V2 && net.arch.pos_freq == 10) { NRF_DISPATCH_MODE1(run_forward, NRF_NET_V2_10, 10, net, mode, k, s, err) }
     if (net.arch.net == NRF_NET_V3 && net.arch.pos_freq == 12) {
         if (!dino) { err = "V3 forward needs per-sample dino features"; return NRF_EINVAL; }
-        NRF_DISPATCH_MODE(run_forward, NetV3, 12, net, mode, k, s, err)
+        if (net.arch.dino_dim == 64) { NRF_DISPATCH_MODE1(run_forward, NRF_NET_V3_12_64, 12, net, mode, k, s, err) }
+        if (net.arch.dino_dim == 128) { NRF_DISPATCH_MODE1(run_forward, NRF_NET_V3_12_128, 12, net, mode, k, s, err) }
     }
     err = "no forward built for this (net, pos_freq)";
     return NRF_EUNSUPPORTED;

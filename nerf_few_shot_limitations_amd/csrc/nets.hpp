@@ -179,10 +179,10 @@ struct NetV2 {
 // The first-layer operand tiles are rebuilt for the second pass (re-encode + re-fetch, scaled) instead of
 // being kept in registers across the first pass: 40 VGPRs cheaper than holding them.
 // ---------------------------------------------------------------------------
-template <class Mode, int NT, int LP>
+template <class Mode, int NT, int LP, int DT_>
 struct NetV3 {
     static constexpr int PT = pe_tiles(LP);
-    static constexpr int DT = 2;                   // dino_dim 64
+    static constexpr int DT = DT_;                 // dino_dim / 32: 2 (single-scale, 64) or 4 (multi-scale, 128)
     static constexpr int KT0 = PT + DT;
     static constexpr int HT = 8;
     static constexpr bool kNeedsDir = true;
@@ -271,12 +271,12 @@ __device__ __forceinline__ DinoTaps dino_taps(const DinoT& d, const float p[3]) 
     return t;
 }
 
-// the 64 fetched channels as two operand tiles for lane half h: register 4g+e of tile t holds channel 32t+8g+4h+e
-template <class Mode>
+// the fetched channels as DT operand tiles for lane half h: register 4g+e of tile t holds channel 32t+8g+4h+e
+template <class Mode, int DT>
 __device__ __forceinline__ void dino_tiles(const float* __restrict__ feat, const DinoTaps& tp, int h, float scale,
-                                           typename Mode::Act (&out)[2]) {
+                                           typename Mode::Act (&out)[DT]) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < DT; ++t) {
         f32x16 e;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {

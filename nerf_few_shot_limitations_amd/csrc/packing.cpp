@@ -150,7 +150,7 @@ bool make_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, NetPlan& p
         // fusion.0, fusion.2, attention.0, attention.2, fusion.0, fusion.2 (the SAME weights, second pass),
         // output_proj, trunk, density_head, feature_head, colour layers.
         if (a.dir_freq < 1 || 3 * a.dir_freq + 2 > 16) { err = "dir_freq must be in 1..4 (one operand tile)"; return false; }
-        if (a.dino_dim != 64) { err = "only dino_dim=64 is built (two operand tiles)"; return false; }
+        if (a.dino_dim != 64 && a.dino_dim != 128) { err = "dino_dim must be 64 (single-scale) or 128 (multi-scale)"; return false; }
         const int n = a.n_layers, de = pe_dim(a.dir_freq), DT = a.dino_dim / 32;
         if (!check(lin, 0, H, pe + a.dino_dim, "dino_fusion.fusion.0", err) || !check(lin, 1, H, H, "dino_fusion.fusion.2", err) ||
             !check(lin, 2, H / 4, H, "dino_fusion.attention.0", err) || !check(lin, 3, 2, H / 4, "dino_fusion.attention.2", err) ||

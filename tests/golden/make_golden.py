@@ -82,8 +82,8 @@ def load_ref_v2(p):
     return dm.eval(), cm.eval()
 
 
-def load_ref_v3(p):
-    m = ref_mlp.NeRFWithDINO(pos_freq=12, dir_freq=4, dino_dim=64, hidden_dim=256, num_density_layers=8)
+def load_ref_v3(p, dino_dim=64):
+    m = ref_mlp.NeRFWithDINO(pos_freq=12, dir_freq=4, dino_dim=dino_dim, hidden_dim=256, num_density_layers=8)
     sd = m.state_dict()
     for k in sd:
         if k in p:
@@ -170,6 +170,11 @@ def main():
     rgb3, dens3 = m3(pos, dirs, dino)
     fused = m3.dino_fusion(m3.pos_encoder(pos), dino)
     save("mlp_v3", pos=npf(pos), dirs=npf(dirs), dino=npf(dino), rgb=npf(rgb3), density=npf(dens3), fused=npf(fused))
+    # multi-scale feature width (multi_scale_dino.py:50 output_dim = 128, experiments/multiscale.yaml)
+    p3w = O.make_weights("v3", seed=3, dino_dim=128)
+    dino_w = torch.from_numpy(O.uniform01(44, 128 * 128).reshape(128, 128) * 2 - 1)
+    rgbw, densw = load_ref_v3(p3w, 128)(pos[:128], dirs[:128], dino_w)
+    save("mlp_v3_d128", pos=npf(pos[:128]), dirs=npf(dirs[:128]), dino=npf(dino_w), rgb=npf(rgbw), density=npf(densw))
 
     # ---------------- a8 projection + bilinear fetch --------------------------------
     Hc = Wc = 400

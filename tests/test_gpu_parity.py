@@ -234,6 +234,18 @@ def test_mlp_v3_golden(N, golden):
         assert maxdiff(rgb, g["rgb"]) <= tol
 
 
+def test_mlp_v3_multiscale_width(N, golden):
+    """experiments/multiscale.yaml: 128-d features (multi_scale_dino.py:50) -> four feature tiles."""
+    g = golden("mlp_v3_d128")
+    m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=128, mma_mode="f32")
+    m.load_state_dict(O.make_weights("v3", 3, dino_dim=128), strict=False)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        rgb, dens = m(T(g["pos"]), T(g["dirs"]), T(g["dino"]))
+    assert maxdiff(rgb, g["rgb"]) <= 2e-5 and maxdiff(dens, g["density"]) <= 2e-5 * max(1.0, float(g["density"].max()))
+    assert m.flops_per_sample() == 2 * (918976 + 2 * 256 * 64)      # SURVEY a7 MAC count + the wider fusion.0 run twice
+
+
 def test_render_v3_end_to_end_golden(N, golden):
     """Config C4 path: project each sample into the source view, bilinear fetch of the feature map, fusion, trunk,
     colour, composite -- one kernel -- against the reference's outputs (train.py:203-242)."""

@@ -132,6 +132,13 @@ def test_mlp_v3_golden(golden):
     close(fused, g["fused"], 2e-6)
 
 
+def test_mlp_v3_multiscale_width_golden(golden):
+    g = golden("mlp_v3_d128")
+    p = O.make_weights("v3", 3, dino_dim=128)
+    rgb, dens = O.mlp_v3(p, T(g["pos"]), T(g["dirs"]), T(g["dino"]))
+    close(rgb, g["rgb"], 2e-6); close(dens, g["density"], 2e-5)
+
+
 def test_param_counts():
     # 477 956 and 821 190 parameters
     assert sum(v.numel() for v in O.make_weights("v1").values()) == 477956

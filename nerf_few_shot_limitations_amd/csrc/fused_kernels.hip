@@ -74,7 +74,8 @@ __device__ __forceinline__ int64_t global_ray(const RenderArgs& a, int64_t i, in
 // ---------------------------------------------------------------------------------------------
 // fused renderer
 // ---------------------------------------------------------------------------------------------
-template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
+// ERT: built with the early-ray-termination machinery (selected when ert_eps > 0); the plain build carries none of it
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
 __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NRF_LDS char* lds = (NRF_LDS char*)smem;
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
 
-    Pipe<WAVES> pipe;
+    Pipe<WAVES, ERT> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
@@ -148,6 +149,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 
         Composite comp;
         comp.reset();
+        pipe.skip = 0;
         float zc[NT], zn[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) zc[n] = z_ray(rid[n], 0);
@@ -189,8 +191,10 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             const float z_own = (own == 0) ? zc[0] : zc[NT - 1];
             const float zn_own = (own == 0) ? zn[0] : zn[NT - 1];
             const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn_own, z_own), norm);
-            const float w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
-                                                              sigmoid_sel<Mode::FAST_EXP>(v[2]), z_own, dist);
+            float w = 0.0f;
+            if (!ERT || !pipe.skip)      // a terminated wave's MLP outputs are stale registers: they must not reach the accumulators
+                w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
+                                                      sigmoid_sel<Mode::FAST_EXP>(v[2]), z_own, dist);
             if (own_valid) {
                 if (a.weights) a.weights[own_rid * S + s] = w;
                 if (a.z_vals) a.z_vals[own_rid * S + s] = z_own;
@@ -198,9 +202,11 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 #pragma unroll
             for (int n = 0; n < NT; ++n) zc[n] = zn[n];
 
-            if (a.ert_eps > 0.0f && !last) {
-                // workgroup-level early termination: every ray of the tile is opaque
+            if (ERT && a.ert_eps > 0.0f && !last) {
+                // early termination: a wave whose rays are all opaque stops computing (pipe.skip), the workgroup
+                // leaves the sample loop once all of its waves have
                 const int wave_dead = __all((!own_valid) || (comp.T < a.ert_eps));
+                pipe.skip = (uint32_t)__builtin_amdgcn_readfirstlane(wave_dead ? 1 : 0);   // provably wave-uniform: scalar branch
                 if (lane == 0) flags[(s & 1) * WAVES + wave] = wave_dead;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -353,9 +359,9 @@ NetArgs net_args(const DeviceNet& net, int mode) {
     return n;
 }
 
-template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
-int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
-    auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD>;
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
+int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
+    auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD, ERT>;
     static int prepared = prepare(kernel, err);
     if (prepared != NRF_OK) return prepared;
     RenderKArgs k;
@@ -368,6 +374,12 @@ int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t 
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("render launch: ") + hipGetErrorString(e); return NRF_EHIP; }
     return NRF_OK;
+}
+
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
+int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
+    if (a.ert_eps > 0.0f) return run_render_v<Net, Mode, NT, WAVES, LP, LD, true>(net, mode, a, s, err);
+    return run_render_v<Net, Mode, NT, WAVES, LP, LD, false>(net, mode, a, s, err);
 }
 
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>

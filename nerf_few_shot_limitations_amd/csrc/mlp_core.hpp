@@ -80,8 +80,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // acquire(X) is called a few fragments BEFORE the reads of chunk X-1 are finished (dense() below), so that the
 // first fragments of chunk X are already in flight while the last MFMAs of chunk X-1 run: that is why the
 // slot recycled at the barrier is the one two chunks back, not one.
-template <int WAVES>
+template <int WAVES, bool CAN_SKIP = false>
 struct Pipe {
+    static constexpr bool kCanSkip = CAN_SKIP;    // early-ray-termination build: a wave may sit out the math (see dense())
     static constexpr int kFragsPerWave = kChunkFrags / WAVES;    // glds instructions per wave per chunk
     static constexpr int kAhead = kSlots - 2;                    // chunks in flight / landed ahead of the reader
     const NRF_GLB char* src;   // packed stream + wave*kFragsPerWave KiB + lane*16
@@ -94,9 +95,11 @@ struct Pipe {
     uint32_t wave_off;         // wave * kFragsPerWave KiB (wave-uniform)
     uint32_t lane_off;         // lane * 16
     uint32_t ablate;           // timing experiments only (NRF_ABLATE): 1 = stop streaming after the first fill, 2 = no barriers
+    uint32_t skip;             // wave-uniform: this wave's rays are all terminated -> keep the stream protocol, skip the math
 
     __device__ __forceinline__ void init(const void* stream, uint32_t chunks, NRF_LDS char* ring_base, uint32_t ablate_flags = 0) {
         ablate = ablate_flags;
+        skip = 0;
         const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
         lane_off = (threadIdx.x & 63) * 16;
         wave_off = wave * (kFragsPerWave * kFragBytes);
@@ -218,6 +221,8 @@ __device__ __forceinline__ void load_bias(f32x16& acc, const NRF_LDS float* bias
 // accumulators.  Fragment reads are software-pipelined kPrefetch deep (LDS latency would otherwise sit in front
 // of every MFMA) and the next chunk is acquired kPrefetch fragments before the current one is used up, so
 // the read stream never stops inside a layer.
+constexpr __host__ __device__ int chunks_for_frags(int frags) { return (frags + kChunkFrags - 1) / kChunkFrags; }
+
 constexpr int kPrefetch = 4;
 constexpr int kEpilogueAt = 3;   // the epilogue of tile m-1 runs after this many fragments of tile m have been issued
 
@@ -229,6 +234,13 @@ __device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,
     constexpr int PF = NF < kPrefetch ? NF : kPrefetch;
     constexpr int EPI = PER_M > kEpilogueAt ? kEpilogueAt : PER_M - 1;
     typedef typename Mode::frag_t frag_t;
+    if constexpr (P::kCanSkip) if (pipe.skip) {
+        // early ray termination, wave level: all 32*NT rays of this wave are opaque.  The wave still takes part in
+        // every chunk hand-over (its share of the LDS-DMA, the barriers) but issues no LDS reads, MFMAs or epilogues.
+#pragma unroll
+        for (int c = 0; c < chunks_for_frags(NF); ++c) pipe.acquire(c & 1);
+        return;
+    }
     frag_t fr[PF];
     auto read = [&](auto g_) -> frag_t {
         constexpr int g = decltype(g_)::value;

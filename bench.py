@@ -45,7 +45,7 @@ def main():
     ap.add_argument("--net", default="v1", choices=["v1", "v2", "v3"])
     ap.add_argument("--scene", default="solid", choices=["fog", "solid"])
     ap.add_argument("--ert", type=float, default=0.0)
-    ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--tile-rows", type=int, default=0, help="rows per pixel tile; 0 = largest <= 16 that deals the tiles evenly")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
     args = ap.parse_args()
 
@@ -102,7 +102,11 @@ def main():
         rz = torch.tensor([[math.cos(th), -math.sin(th), 0, 0], [math.sin(th), math.cos(th), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
         poses.append(rz @ c2w)
     poses = torch.stack(poses)
-    tile_rays = args.tile_rows * W
+    tile_rows = args.tile_rows
+    if tile_rows <= 0:
+        even = [r for r in range(16, 0, -1) if H % r == 0 and (H // r) % world == 0]
+        tile_rows = even[0] if even else 16
+    tile_rays = tile_rows * W
     job = tiles.TileJob(model, H, W, focal, poses, 2.0, 6.0, S, rank, world, tile_rays, ert_eps=args.ert, device=dev, dino=dino)
     ev = []
 
@@ -163,7 +167,7 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.mode, "data": "synthetic",
         "config": {"workload": f"{H}x{W} camera frame x {S} samples/ray, NeRFMLP {args.net} 8x256, scene {args.scene}, "
-                               f"{n_frames} view(s)/step, {args.tile_rows}-row pixel tiles dealt round-robin over {world} GPU(s), one launch + one all_gather per step",
+                               f"{n_frames} view(s)/step, {tile_rows}-row pixel tiles dealt round-robin over {world} GPU(s), one launch + one all_gather per step",
                    "rays_per_gpu_per_step": job.rays_per_launch, "samples_per_ray": S, "ert_eps": args.ert,
                    "flops_per_sample": flops_per_sample, "parallelism": f"pixel-tile x{world}"},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.mode], "unit": "TFLOP/s",

@@ -12,7 +12,7 @@ import threading
 import torch  # imported BEFORE the library on purpose: libnerfhip.so then binds to the HIP runtime torch already loaded
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libnerfhip.so")
+LIB_PATH = os.environ.get("NRF_LIB") or os.path.join(_PKG, "libnerfhip.so")     # NRF_LIB: A/B another build of the same ABI
 
 NRF_NET_V1, NRF_NET_V2, NRF_NET_V3 = 1, 2, 3
 MMA_MODES = {"bf16": 0, "f16": 1, "f32": 2}

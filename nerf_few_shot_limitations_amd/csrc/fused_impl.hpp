@@ -1,0 +1,450 @@
+// fused_impl.hpp -- the fused sample -> encode -> MLP -> composite renderer and the staged MLP
+// forward, hand-written for gfx950 (CDNA4).  See mlp_core.hpp for the MFMA / weight-stream design.
+//
+// Work mapping of the renderer: a persistent workgroup (4 waves, one per SIMD, 1 workgroup per CU
+// because of its 145 KiB of LDS) walks ray tiles of 4*32*NT rays.  Inside a wave LANE <-> RAY: the
+// wave marches its 32*NT rays front to back, one sample per ray per MLP pass, so a ray's
+// transmittance / colour / depth accumulators live in the registers of the lane that owns it
+// (lane (c,h) owns ray 32h+c of the wave) and a whole workgroup stops marching a tile as soon as
+// every one of its rays has T < ert_eps.
+#pragma once
+#include <cstdlib>
+
+#include "kernels.hpp"
+#include "nets.hpp"
+
+namespace nrf {
+
+constexpr int kBiasMaxFloats = 4096;                                   // 16 KiB bias table
+constexpr int kLdsRing = kSlots * kChunkBytes;                         // 128 KiB
+constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64;          // + ERT flags
+
+struct NetArgs {
+    const void* stream;
+    const float* bias;
+    uint32_t n_chunks;
+    int n_bias;
+    int n_layers;
+    uint32_t ablate;
+};
+
+struct RenderKArgs {
+    NetArgs net;
+    RenderArgs a;
+    int64_t n_tiles;
+};
+
+struct ForwardKArgs {
+    NetArgs net;
+    const float* x_enc;      // V1: (P, pe_dim)
+    const float* pos;        // V2/V3: (P,3)
+    const float* dir;        // V2/V3: (P,3)
+    const float* dino;       // V3: (P,dino_dim)
+    int64_t n;
+    float* out4;             // V1: (P,4)
+    float* rgb;              // V2/V3: (P,3)
+    float* density;          // V2/V3: (P,1)
+    int64_t n_tiles;
+};
+
+template <bool FAST>
+__device__ __forceinline__ float sigmoid_sel(float x) { return FAST ? sigmoid_fast(x) : sigmoid_precise(x); }
+
+__device__ __forceinline__ void load_bias_table(NRF_LDS float* bias, const float* src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) bias[i] = src[i];
+    __syncthreads();
+}
+
+// local ray index -> (view of the batch, global ray id inside that view); pixel-tile sharding: SURVEY.md section 8e
+__device__ __forceinline__ int64_t global_ray(const RenderArgs& a, int64_t i, int& cam) {
+    cam = 0;
+    if (!a.camera_mode) return i;
+    if (a.n_cams > 1) {
+        cam = (int)(i / a.rays_per_cam);
+        i -= (int64_t)cam * a.rays_per_cam;
+    }
+    int64_t g = a.ray_begin + i;
+    if (a.tile_rays < a.rays_per_cam) {
+        const int64_t k = i / a.tile_rays;
+        g = a.ray_begin + k * a.tile_stride + (i - k * a.tile_rays);
+    }
+    const int64_t last = (int64_t)a.cams[0].H * a.cams[0].W - 1;
+    return g < last ? g : last;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused renderer
+// ---------------------------------------------------------------------------------------------
+// ERT: built with the early-ray-termination machinery (selected when ert_eps > 0); the plain build carries none of it
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
+__global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NRF_LDS char* lds = (NRF_LDS char*)smem;
+    NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
+    NRF_LDS int* flags = (NRF_LDS int*)(bias + kBiasMaxFloats);
+    typedef typename Mode::Act Act;
+    constexpr int KT0 = pe_tiles(LP);
+    constexpr int TILE = WAVES * 32 * NT;
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    load_bias_table(bias, P.net.bias, P.net.n_bias);
+
+    Pipe<WAVES, ERT> pipe;
+    pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
+    pipe.start();
+
+    const RenderArgs& a = P.a;
+    const int S = a.n_samples;
+    const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, a.z_ladder);
+    const int own = (NT == 2) ? h : 0;
+    const bool owner = h < NT;
+
+    for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        int64_t rid[NT];
+        float o[NT][3], d[NT][3];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t r = tile * TILE + wave * (32 * NT) + 32 * n + c;
+            rid[n] = r < a.n_rays ? r : a.n_rays - 1;
+            if (a.camera_mode) {
+                int ci;
+                const int64_t g = global_ray(a, rid[n], ci);
+                camera_ray(a.cams[ci], g, o[n], d[n]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { o[n][k] = a.rays_o[rid[n] * 3 + k]; d[n][k] = a.rays_d[rid[n] * 3 + k]; }
+            }
+        }
+        const int64_t own_rid = (own == 0) ? rid[0] : rid[NT - 1];
+        const int64_t own_raw = tile * TILE + wave * (32 * NT) + 32 * own + c;
+        const bool own_valid = owner && own_raw < a.n_rays;
+        float own_d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) own_d[k] = (own == 0) ? d[0][k] : d[NT - 1][k];
+        const float norm = ray_norm(own_d);
+
+        Act dirT[1][NT];
+        if constexpr (Net::kNeedsDir) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                Act t1[pe_tiles(LD)];
+                encode3<Mode, LD>(d[n], h, t1);          // view direction = raw rays_d (train.py:225)
+                dirT[0][n] = t1[0];
+            }
+        }
+
+        auto z_ray = [&](int64_t ray, int s) -> float {
+            if (a.z_in) return a.z_in[ray * S + s];
+            if (!a.perturb) return ladder_z(lad, s);
+            float u;
+            if (a.t_rand) {
+                u = a.t_rand[ray * S + s];
+            } else {
+                int ci;
+                const int64_t g = global_ray(a, ray, ci);
+                u = counter_uniform(a.seed + (uint64_t)ci * 0x51ED27ull, (uint64_t)g, (uint32_t)s);
+            }
+            return ladder_z_jitter(lad, s, u);
+        };
+
+        Composite comp;
+        comp.reset();
+        pipe.skip = 0;
+        float zc[NT], zn[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) zc[n] = z_ray(rid[n], 0);
+
+        int s = 0;
+        for (; s < S; ++s) {
+            const bool last = (s + 1 == S);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) zn[n] = last ? 0.0f : z_ray(rid[n], s + 1);
+
+            // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
+            auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float p[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[k] = point_on_ray(o[n][k], d[n][k], zc[n]);
+                    Act e1[KT0];
+                    encode3<Mode, LP>(p, h, e1, w0[n]);
+#pragma unroll
+                    for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
+                    if constexpr (Net::kDino) {
+                        constexpr int DT = Net::KT0 - KT0;
+                        const DinoTaps tp = dino_taps(a.dino, p);
+                        Act dt[DT];
+                        dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
+#pragma unroll
+                        for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
+                    }
+                }
+            };
+
+            float out4[NT][4];
+            Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
+
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (own == 0) ? out4[0][k] : out4[NT - 1][k];
+            const float z_own = (own == 0) ? zc[0] : zc[NT - 1];
+            const float zn_own = (own == 0) ? zn[0] : zn[NT - 1];
+            const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn_own, z_own), norm);
+            float w = 0.0f;
+            if (!ERT || !pipe.skip)      // a terminated wave's MLP outputs are stale registers: they must not reach the accumulators
+                w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
+                                                      sigmoid_sel<Mode::FAST_EXP>(v[2]), z_own, dist);
+            if (own_valid) {
+                if (a.weights) a.weights[own_rid * S + s] = w;
+                if (a.z_vals) a.z_vals[own_rid * S + s] = z_own;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) zc[n] = zn[n];
+
+            if (ERT && a.ert_eps > 0.0f && !last) {
+                // early termination: a wave whose rays are all opaque stops computing (pipe.skip), the workgroup
+                // leaves the sample loop once all of its waves have
+                const int wave_dead = __all((!own_valid) || (comp.T < a.ert_eps));
+                pipe.skip = (uint32_t)__builtin_amdgcn_readfirstlane(wave_dead ? 1 : 0);   // provably wave-uniform: scalar branch
+                if (lane == 0) flags[(s & 1) * WAVES + wave] = wave_dead;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const NRF_LDS int* fl = flags + (s & 1) * WAVES;
+                int all_dead = 1;
+#pragma unroll
+                for (int wv = 0; wv < WAVES; ++wv) all_dead &= fl[wv];
+                if (all_dead) { ++s; break; }
+            }
+        }
+        if (own_valid) {
+            // samples skipped by early termination carry weight < ert_eps: report 0 and their depths
+            for (int s2 = s; s2 < S; ++s2) {
+                if (a.weights) a.weights[own_rid * S + s2] = 0.0f;
+                if (a.z_vals) a.z_vals[own_rid * S + s2] = z_ray(own_rid, s2);
+            }
+            float r = comp.r, g = comp.g, b = comp.b;
+            if (a.white_bkgd) {                                      // nerf_mlp.py:209-212
+                const float bg = __fsub_rn(1.0f, comp.acc);
+                r = __fadd_rn(r, bg); g = __fadd_rn(g, bg); b = __fadd_rn(b, bg);
+            }
+            a.rgb[own_rid * 3 + 0] = r;
+            a.rgb[own_rid * 3 + 1] = g;
+            a.rgb[own_rid * 3 + 2] = b;
+            a.depth[own_rid] = comp.depth;
+        }
+    }
+    pipe.drain();
+}
+
+// ---------------------------------------------------------------------------------------------
+// staged MLP forward on explicit per-sample inputs (NeRFMLP.forward drop-in)
+// ---------------------------------------------------------------------------------------------
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
+__global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NRF_LDS char* lds = (NRF_LDS char*)smem;
+    NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
+    typedef typename Mode::Act Act;
+    constexpr int KT0 = pe_tiles(LP);
+    constexpr int TILE = WAVES * 32 * NT;
+    constexpr int PE = pe_dim(LP);
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    load_bias_table(bias, P.net.bias, P.net.n_bias);
+    Pipe<WAVES> pipe;
+    pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
+    pipe.start();
+    const int own = (NT == 2) ? h : 0;
+    const bool owner = h < NT;
+
+    for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        int64_t sid[NT];
+        Act dirT[1][NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int64_t r = tile * TILE + wave * (32 * NT) + 32 * n + c;
+            sid[n] = r < P.n ? r : P.n - 1;
+            if constexpr (Net::kNeedsDir) {
+                float dd[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dd[k] = P.dir[sid[n] * 3 + k];
+                Act t1[pe_tiles(LD)];
+                encode3<Mode, LD>(dd, h, t1);
+                dirT[0][n] = t1[0];
+            }
+        }
+        auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                if constexpr (Net::kNeedsDir) {
+                    float p[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) p[k] = P.pos[sid[n] * 3 + k];
+                    Act e1[KT0];
+                    encode3<Mode, LP>(p, h, e1, w0[n]);
+#pragma unroll
+                    for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
+                    if constexpr (Net::kDino) {
+                        // features handed over per sample (NeRFMLP.forward's third argument): channel 32t+8g+4h+q
+                        constexpr int DT = Net::KT0 - KT0;
+                        const float* f = P.dino + sid[n] * (32 * DT);
+#pragma unroll
+                        for (int t = 0; t < DT; ++t) {
+                            f32x16 e;
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const f32x4 v = *(const f32x4*)(f + 32 * t + 8 * g + 4 * h);
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) e[4 * g + q] = v[q] * w1[n];
+                            }
+                            x[KT0 + t][n] = Mode::template to_act<false>(e);
+                        }
+                    }
+                } else {
+                    // gather the already-encoded features into operand order (feature_map.hpp)
+                    const float* xin = P.x_enc + sid[n] * PE;
+                    f32x16 e[KT0];
+                    static_for<16 * KT0>([&](auto u_) {
+                        constexpr int u = decltype(u_)::value;
+                        constexpr int i0 = pe_ref_index(LP, u, 0), i1 = pe_ref_index(LP, u, 1);
+                        float val = 0.0f;
+                        if constexpr (i0 >= 0 && i1 >= 0) val = xin[h ? i1 : i0];
+                        else if constexpr (i0 >= 0) val = h ? 0.0f : xin[i0];
+                        else if constexpr (i1 >= 0) val = h ? xin[i1] : 0.0f;
+                        e[u / 16][u % 16] = val;
+                    });
+#pragma unroll
+                    for (int t = 0; t < KT0; ++t) x[t][n] = Mode::template to_act<false>(e[t]);
+                }
+            }
+        };
+        float out4[NT][4];
+        Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
+        const int64_t own_raw = tile * TILE + wave * (32 * NT) + 32 * own + c;
+        if (owner && own_raw < P.n) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (own == 0) ? out4[0][k] : out4[NT - 1][k];
+            const float r = sigmoid_sel<Mode::FAST_EXP>(v[0]), g = sigmoid_sel<Mode::FAST_EXP>(v[1]), b = sigmoid_sel<Mode::FAST_EXP>(v[2]);
+            if constexpr (Net::kNeedsDir) {
+                P.rgb[own_raw * 3 + 0] = r; P.rgb[own_raw * 3 + 1] = g; P.rgb[own_raw * 3 + 2] = b;
+                P.density[own_raw] = fmaxf(v[3], 0.0f);                 // nerf_mlp.py:63
+            } else {
+                *(float4*)(P.out4 + own_raw * 4) = make_float4(r, g, b, v[3]);   // nerf_model.py:22-24
+            }
+        }
+    }
+    pipe.drain();
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+template <class K>
+int prepare(K kernel, std::string& err) {
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return NRF_EHIP; }
+    return NRF_OK;
+}
+
+NetArgs net_args(const DeviceNet& net, int mode) {
+    NetArgs n;
+    n.stream = net.stream[mode]; n.bias = net.bias; n.n_chunks = net.n_chunks[mode]; n.n_bias = net.n_bias; n.n_layers = net.arch.n_layers;
+    static const uint32_t ablate = [] { const char* e = getenv("NRF_ABLATE"); return e ? (uint32_t)atoi(e) : 0u; }();
+    n.ablate = ablate;   // timing experiments only: results are wrong when set
+    return n;
+}
+
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
+int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
+    auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD, ERT>;
+    static int prepared = prepare(kernel, err);
+    if (prepared != NRF_OK) return prepared;
+    RenderKArgs k;
+    k.net = net_args(net, mode);
+    k.a = a;
+    constexpr int TILE = WAVES * 32 * NT;
+    k.n_tiles = (a.n_rays + TILE - 1) / TILE;
+    const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("render launch: ") + hipGetErrorString(e); return NRF_EHIP; }
+    return NRF_OK;
+}
+
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
+int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
+    if (a.ert_eps > 0.0f) return run_render_v<Net, Mode, NT, WAVES, LP, LD, true>(net, mode, a, s, err);
+    return run_render_v<Net, Mode, NT, WAVES, LP, LD, false>(net, mode, a, s, err);
+}
+
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
+int run_forward(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) {
+    auto kernel = forward_kernel<Net, Mode, NT, WAVES, LP, LD>;
+    static int prepared = prepare(kernel, err);
+    if (prepared != NRF_OK) return prepared;
+    k.net = net_args(net, mode);
+    constexpr int TILE = WAVES * 32 * NT;
+    k.n_tiles = (k.n + TILE - 1) / TILE;
+    const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("forward launch: ") + hipGetErrorString(e); return NRF_EHIP; }
+    return NRF_OK;
+}
+
+bool check_net(const DeviceNet& net, int mode, std::string& err) {
+    if (mode < 0 || mode > 2) { err = "unknown mma_mode"; return false; }
+    if (net.n_bias > kBiasMaxFloats) { err = "bias table exceeds the LDS carve-out"; return false; }
+    if (net.arch.dir_freq != 4 && net.arch.net != NRF_NET_V1) { err = "only dir_freq=4 is built"; return false; }
+    return true;
+}
+
+}  // namespace
+
+// Workgroup geometry per arithmetic mode: 16-bit modes run 8 waves x 32 samples (two waves per SIMD, <= 256
+// registers, each covering the other's epilogue / waits); NRF_GEOMETRY=4x2 selects 4 waves x 64 samples (V1 only).
+// The fp32 mode keeps 4 waves x 32 samples (its fp32 activations need > 256 registers).
+static bool wide_waves() {
+    static const bool w = [] { const char* e = getenv("NRF_GEOMETRY"); return !(e && std::string(e) == "4x2"); }();
+    return w;
+}
+
+#define NRF_DISPATCH_MODE(FN, NET, LP, ...)                                                                 \
+    switch (mode) {                                                                                         \
+        case NRF_MMA_BF16:                                                                                  \
+            if (wide_waves()) return FN<NET<ModeBF16, 1, LP>, ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);         \
+            return FN<NET<ModeBF16, 2, LP>, ModeBF16, 2, 4, LP, 4>(__VA_ARGS__);                            \
+        case NRF_MMA_F16:                                                                                   \
+            if (wide_waves()) return FN<NET<ModeF16, 1, LP>, ModeF16, 1, 8, LP, 4>(__VA_ARGS__);           \
+            return FN<NET<ModeF16, 2, LP>, ModeF16, 2, 4, LP, 4>(__VA_ARGS__);                              \
+        default: return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                         \
+    }
+
+// V2 / V3: one geometry per mode (8 waves x 32 samples for the 16-bit modes, 4 x 32 for fp32)
+#define NRF_DISPATCH_MODE1(FN, NETT, LP, ...)                                                               \
+    switch (mode) {                                                                                         \
+        case NRF_MMA_BF16: return FN<NETT(ModeBF16), ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);                   \
+        case NRF_MMA_F16:  return FN<NETT(ModeF16), ModeF16, 1, 8, LP, 4>(__VA_ARGS__);                     \
+        default:           return FN<NETT(ModeF32), ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                     \
+    }
+#define NRF_NET_V2_10(M) NetV2<M, 1, 10>
+#define NRF_NET_V3_12_64(M) NetV3<M, 1, 12, 2>
+#define NRF_NET_V3_12_128(M) NetV3<M, 1, 12, 4>
+
+// per-family entry points, one translation unit each (fused_v1.hip ... fused_v3w.hip) so that hipcc builds them in parallel
+int render_v1(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
+int render_v2(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
+int render_v3(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
+int render_v3w(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
+int forward_v1(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
+int forward_v2(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
+int forward_v3(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
+int forward_v3w(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
+
+}  // namespace nrf

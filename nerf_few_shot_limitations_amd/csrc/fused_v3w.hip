@@ -1,0 +1,9 @@
+// fused_v3w.hip -- V3 with 128-d (multi-scale) features
+#include "fused_impl.hpp"
+
+namespace nrf {
+
+int render_v3w(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE1(run_render, NRF_NET_V3_12_128, 12, net, mode, a, s, err) }
+int forward_v3w(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE1(run_forward, NRF_NET_V3_12_128, 12, net, mode, k, s, err) }
+
+}  // namespace nrf

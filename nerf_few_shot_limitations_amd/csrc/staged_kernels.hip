@@ -77,32 +77,70 @@ __global__ void __launch_bounds__(kBlock) encode_kernel(const float* __restrict_
 }
 
 // ---- a9/a10: nerf_mlp.py:165-215, volume_renderer.py:4-43 ------------------------------------
+// HBM-bound: 20 B read (+4 B written when weights are requested) per ray-sample.  One WAVE per ray, LANE <-> sample, so
+// every load/store of z, sigma, rgb and weights is a contiguous 64-element segment of the reference's (R,S,*) rows; the
+// exclusive transmittance product (cumprod, :196-199) is a wave prefix product, the four sums are wave reductions.
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float u = __shfl_up(v, d, 64);
+        if (lane >= d) v = __fmul_rn(v, u);
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = __fadd_rn(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
 __global__ void __launch_bounds__(kBlock) composite_kernel(const float* __restrict__ rgb, int rgb_stride, const float* __restrict__ sigma,
                                                            int sigma_stride, const float* __restrict__ z, const float* __restrict__ rays_d,
                                                            int64_t n_rays, int S, int white_bkgd, float* __restrict__ out_rgb,
                                                            float* __restrict__ out_depth, float* __restrict__ out_w) {
-    for (int64_t r = blockIdx.x * (int64_t)kBlock + threadIdx.x; r < n_rays; r += (int64_t)gridDim.x * kBlock) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    for (int64_t r = wave0; r < n_rays; r += n_waves) {
         const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
         const float norm = ray_norm(d);
-        Composite c;
-        c.reset();
-        float zc = z[r * S];
-        for (int s = 0; s < S; ++s) {
-            const int64_t i = r * S + s;
+        float T_in = 1.0f;                                   // transmittance entering this 64-sample segment
+        float sr = 0.0f, sg = 0.0f, sb = 0.0f, sd = 0.0f, sa = 0.0f;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const bool valid = s < S;
+            const int64_t i = r * S + (valid ? s : S - 1);
+            const float zc = z[i];
+            float zn = __shfl_down(zc, 1, 64);
+            if (lane == 63 && s + 1 < S) zn = z[i + 1];
             const bool last = (s + 1 == S);
-            const float zn = last ? 0.0f : z[i + 1];
             const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
-            const float w = c.add<false>(sigma[i * sigma_stride], rgb[i * rgb_stride], rgb[i * rgb_stride + 1], rgb[i * rgb_stride + 2], zc, dist);
-            if (out_w) out_w[i] = w;
-            zc = zn;
+            float alpha = 0.0f;
+            if (valid) alpha = __fsub_rn(1.0f, expf(__fmul_rn(-fmaxf(sigma[i * sigma_stride], 0.0f), dist)));
+            const float f = valid ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+            const float incl = wave_incl_prod(f, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float w = __fmul_rn(alpha, __fmul_rn(T_in, excl));
+            if (valid) {
+                if (out_w) out_w[i] = w;
+                sr = __fadd_rn(sr, __fmul_rn(w, rgb[i * rgb_stride]));
+                sg = __fadd_rn(sg, __fmul_rn(w, rgb[i * rgb_stride + 1]));
+                sb = __fadd_rn(sb, __fmul_rn(w, rgb[i * rgb_stride + 2]));
+                sd = __fadd_rn(sd, __fmul_rn(w, zc));
+                sa = __fadd_rn(sa, w);
+            }
+            T_in = __fmul_rn(T_in, __shfl(incl, 63, 64));
         }
-        float cr = c.r, cg = c.g, cb = c.b;
-        if (white_bkgd) {
-            const float bg = __fsub_rn(1.0f, c.acc);
-            cr = __fadd_rn(cr, bg); cg = __fadd_rn(cg, bg); cb = __fadd_rn(cb, bg);
+        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+        if (lane == 0) {
+            if (white_bkgd) {
+                const float bg = __fsub_rn(1.0f, sa);
+                sr = __fadd_rn(sr, bg); sg = __fadd_rn(sg, bg); sb = __fadd_rn(sb, bg);
+            }
+            out_rgb[r * 3] = sr; out_rgb[r * 3 + 1] = sg; out_rgb[r * 3 + 2] = sb;
+            if (out_depth) out_depth[r] = sd;
         }
-        out_rgb[r * 3] = cr; out_rgb[r * 3 + 1] = cg; out_rgb[r * 3 + 2] = cb;
-        if (out_depth) out_depth[r] = c.depth;
     }
 }
 
@@ -238,7 +276,7 @@ int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, 
 int launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
                      int64_t n_rays, int S, int white_bkgd, float* out_rgb, float* out_depth, float* out_w, hipStream_t s) {
     if (n_rays <= 0) return NRF_OK;
-    hipLaunchKernelGGL(composite_kernel, dim3(grid_for(n_rays, kBlock, 8192)), dim3(kBlock), 0, s, rgb, rgb_stride, sigma, sigma_stride, z,
+    hipLaunchKernelGGL(composite_kernel, dim3(grid_for(n_rays * 64, kBlock, 16384)), dim3(kBlock), 0, s, rgb, rgb_stride, sigma, sigma_stride, z,
                        rays_d, n_rays, S, white_bkgd, out_rgb, out_depth, out_w);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }

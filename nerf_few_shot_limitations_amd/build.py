@@ -53,24 +53,44 @@ def _compile(src: str, verbose: bool) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile (if stale) and return the path of libnerfhip.so."""
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, obj_dir: str = OBJ) -> str:
+    """Compile (if stale) and return the path of libnerfhip.so.  `extra_flags`/`out`/`obj_dir` build a tuning variant
+    beside the product (loaded with NRF_LIB=<path> for same-process-free A/B runs on one GPU box)."""
     deps = _deps()
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= _newest(deps):
-        return LIB
-    os.makedirs(OBJ, exist_ok=True)
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest(deps):
+        return out
+    os.makedirs(obj_dir, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc(), *FLAGS, *extra_flags, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
     with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, verbose), SOURCES))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp", *objs]
+        objs = list(ex.map(one, SOURCES))
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out + ".tmp", *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    path = build(force="--force" in sys.argv, verbose=True)
+    # python -m nerf_few_shot_limitations_amd.build [--force] [--variant NAME -DNRF_PREFETCH=6 ...]
+    argv = sys.argv[1:]
+    if "--variant" in argv:
+        name = argv[argv.index("--variant") + 1]
+        flags = [a for a in argv if a.startswith("-D")]
+        path = build(force=True, verbose=False, extra_flags=flags, out=os.path.join(PKG, f"libnerfhip_{name}.so"),
+                     obj_dir=os.path.join(PKG, "build", name))
+    else:
+        path = build(force="--force" in argv, verbose=True)
     print(path)

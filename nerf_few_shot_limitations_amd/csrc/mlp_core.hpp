@@ -24,6 +24,8 @@
 #include <stdint.h>
 #include <utility>
 
+#include "stream_config.hpp"
+
 namespace nrf {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -54,9 +56,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define NRF_GLB __attribute__((address_space(1)))
 
 constexpr int kFragBytes = 1024;                     // 64 lanes x 16 B
-constexpr int kChunkFrags = 16;
+constexpr int kChunkFrags = NRF_CHUNK_FRAGS;
 constexpr int kChunkBytes = kFragBytes * kChunkFrags;  // 16 KiB
-constexpr int kSlots = 8;                              // ring depth (128 KiB)
+constexpr int kSlots = NRF_SLOTS;                      // ring depth (128 KiB)
 
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
@@ -223,8 +225,14 @@ __device__ __forceinline__ void load_bias(f32x16& acc, const NRF_LDS float* bias
 // the read stream never stops inside a layer.
 constexpr __host__ __device__ int chunks_for_frags(int frags) { return (frags + kChunkFrags - 1) / kChunkFrags; }
 
-constexpr int kPrefetch = 4;
-constexpr int kEpilogueAt = 3;   // the epilogue of tile m-1 runs after this many fragments of tile m have been issued
+#ifndef NRF_PREFETCH
+#define NRF_PREFETCH 3
+#endif
+#ifndef NRF_EPILOGUE_AT
+#define NRF_EPILOGUE_AT 3
+#endif
+constexpr int kPrefetch = NRF_PREFETCH;
+constexpr int kEpilogueAt = NRF_EPILOGUE_AT;   // the epilogue of tile m-1 runs after this many fragments of tile m have been issued
 
 template <class Mode, int KT, int MT, int NT, class P, class Fin>
 __device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,

@@ -5,11 +5,12 @@
 #include <cstring>
 
 #include "feature_map.hpp"
+#include "stream_config.hpp"
 
 namespace nrf {
 
 namespace {
-constexpr int kFragBytes = 1024, kChunkFrags = 16;
+constexpr int kFragBytes = 1024, kChunkFrags = NRF_CHUNK_FRAGS;
 
 uint32_t f32_bits(float x) { uint32_t u; std::memcpy(&u, &x, 4); return u; }
 }  // namespace

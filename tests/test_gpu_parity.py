@@ -436,6 +436,80 @@ def test_full_frame_properties_800x800x64(N):
     assert maxdiff(r32, ref["rgb"]) <= TOL and maxdiff(d32, ref["depth"]) <= TOL
 
 
+@pytest.mark.parametrize("S", [2, 192])
+def test_render_sample_count_extremes(N, S):
+    """S=2 (one interval + the 1e10 tail) and S=192 (the fine pass of config 3) against the oracle, fp32 mode."""
+    H, W = 9, 31
+    c2w = T(O.LEGO_LIKE_C2W)
+    m, p = model_v1(N, "fog", "f32")
+    rgb, depth = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
+    ro, rd = O.get_rays(H, W, O.focal_for(W), c2w)
+    ref = O.render_rays(p, "v1", ro, rd, 2.0, 6.0, S)
+    assert maxdiff(rgb, ref["rgb"]) <= TOL and maxdiff(depth, ref["depth"]) <= TOL
+
+
+def test_render_lindisp_white_background_and_shallow_nets(N):
+    H, W, S = 11, 13, 24
+    c2w = T(O.LEGO_LIKE_C2W)
+    ro, rd = O.get_rays(H, W, O.focal_for(W), c2w)
+    # lindisp sampling (ray_utils.py:59-62) + white background (nerf_mlp.py:209-212)
+    m, p = model_v1(N, "fog", "f32")
+    out = N.render_rays(m, ro, rd, 2.0, 6.0, S, lindisp=True, white_bkgd=True, return_z=True)
+    with torch.no_grad():
+        pts, z = O.sample_points_along_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 2.0, 6.0, S, lindisp=True)
+        o4 = O.mlp_v1(p, O.positional_encoding(pts.reshape(-1, 3), 10))
+        c, dep, w = O.volume_render(o4[:, :3].reshape(-1, S, 3), o4[:, 3:].reshape(-1, S, 1), z, rd.reshape(-1, 3), white_bkgd=True)
+    assert maxdiff(out["z_vals"], z) <= 1e-6
+    assert maxdiff(out["rgb"], c) <= TOL and maxdiff(out["depth"], dep) <= TOL and maxdiff(out["weights"], w) <= TOL
+    # trunks of other depths walk the even/odd buffer paths of the kernel (nets.hpp): V1 with 5 layers, V2 with 3 and 4
+    m5, p5 = model_v1(N, "fog", "f32", n_layers=5)
+    ref = O.render_rays(p5, "v1", ro, rd, 2.0, 6.0, S)
+    out = N.render_rays(m5, ro, rd, 2.0, 6.0, S)
+    assert maxdiff(out["rgb"], ref["rgb"]) <= TOL and maxdiff(out["depth"], ref["depth"]) <= TOL
+    for nl in (3, 4):
+        mv = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=nl, use_dino=False, mma_mode="f32")
+        pv = O.make_weights("v2", 5, "fog", n_layers=nl)
+        mv.load_state_dict(pv, strict=False)
+        mv = mv.cuda().eval()
+        ref = O.render_rays(pv, "v2", ro, rd, 2.0, 6.0, S)
+        out = N.render_rays(mv, ro, rd, 2.0, 6.0, S)
+        assert maxdiff(out["rgb"], ref["rgb"]) <= TOL and maxdiff(out["depth"], ref["depth"]) <= TOL
+
+
+def test_internal_jitter_is_keyed_by_global_ray_id(N):
+    """perturb=True without t_rand: the counter RNG is keyed by (seed, global ray id, sample), so the frame does not depend
+    on how it is cut into launches or tiles, repeats for a seed and changes with it."""
+    from nerf_few_shot_limitations_amd import tiles
+    H, W, S = 24, 40, 16
+    c2w = T(O.LEGO_LIKE_C2W)
+    m, _ = model_v1(N, "solid", "bf16")
+    a = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, perturb=True, seed=7)
+    b = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, perturb=True, seed=7)
+    c = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, perturb=True, seed=8)
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[0], c[0])
+    parts = [N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, perturb=True, seed=7, ray_begin=r, ray_end=r + 8 * W)
+             for r in range(0, H * W, 8 * W)]
+    assert torch.equal(torch.cat([q[0] for q in parts]), a[0])
+    g = torch.stack([tiles.render_tiles(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, r, 2, 4 * W, perturb=True, seed=7) for r in range(2)])
+    frame = tiles.reassemble(g[:, 0], H * W, 2, 4 * W)
+    assert torch.equal(frame[:, :3], a[0]) and torch.equal(frame[:, 3], a[1])
+
+
+def test_trainer_shaped_surface(N):
+    """NeRFRenderer.render_rays(rays_o, rays_d, view_idx, N_samples) / render_full_image(...) (train.py:188, evaluate.py:65)."""
+    H, W = 16, 16
+    c2w = T(O.LEGO_LIKE_C2W)
+    m, p = model_v2(N, "fog", "f32")
+    r = N.NeRFRenderer(m, 2.0, 6.0)
+    ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
+    out = r.render_rays(ro.view(-1, 3), rd.view(-1, 3), 0, 32)
+    assert set(out) == {"rgb", "depth", "weights"} and out["weights"].shape == (H * W, 32)
+    ref = O.render_rays(p, "v2", ro.cpu(), rd.cpu(), 2.0, 6.0, 32)
+    assert maxdiff(out["rgb"], ref["rgb"]) <= TOL
+    img = r.render_full_image(ro, rd, 0, chunk_size=1024, N_samples=32)
+    assert img.shape == (H, W, 3) and np.abs(img - ref["rgb"].reshape(H, W, 3).numpy()).max() <= TOL
+
+
 def test_empty_and_bad_arguments(N):
     from nerf_few_shot_limitations_amd._lib import NrfError
     m, _ = model_v1(N)

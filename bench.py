@@ -17,7 +17,8 @@ The JSON line also carries
                   the launch stream) against the dense bf16 MFMA peak (2.5 PFLOP/s);
   cpu_baseline -- the CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch CPU
                   path) timed on a band of rows of the same frame on this host's cores;
-  parity       -- max abs error / PSNR of the benchmarked mode vs that oracle band.
+  parity       -- max abs error / PSNR of the benchmarked mode (and of the fp32 parity mode) vs that oracle band, and the
+                  PSNR delta of both against a common ground truth (the band marched with 2x the samples).
 """
 import argparse
 import json
@@ -201,8 +202,15 @@ def main():
         rgb_b, depth_b = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, ert_eps=args.ert, device=dev, dino=dino)
         rgb32, depth32 = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f32", device=dev, dino=dino)
         torch.cuda.synchronize()
+        # PSNR delta against a common ground truth (the lego images are not available offline: SURVEY.md section 8d):
+        # GT = the same rows marched with twice the samples by the CPU oracle; both renderers at S samples vs that GT
+        gt = O.render_rays(p, args.net, ro, rd, 2.0, 6.0, 2 * S, chunk=2048, dino=dino)["rgb"]
+        ps_ref = O.psnr(ref["rgb"], gt)
         out["parity"] = {
             "band_rows": rows,
+            "psnr_oracle_vs_gt_db": round(ps_ref, 3),
+            f"psnr_delta_{args.mode}_db": round(abs(O.psnr(rgb_b.cpu(), gt) - ps_ref), 4),
+            "psnr_delta_f32_db": round(abs(O.psnr(rgb32.cpu(), gt) - ps_ref), 6),
             f"{args.mode}_max_abs_rgb": float((rgb_b.cpu() - ref["rgb"]).abs().max()),
             f"{args.mode}_max_abs_depth": float((depth_b.cpu() - ref["depth"]).abs().max()),
             f"{args.mode}_psnr_vs_oracle_db": round(O.psnr(rgb_b.cpu(), ref["rgb"]), 2),

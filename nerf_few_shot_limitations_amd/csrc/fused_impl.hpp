@@ -127,15 +127,15 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
         for (int k = 0; k < 3; ++k) own_d[k] = (own == 0) ? d[0][k] : d[NT - 1][k];
         const float norm = ray_norm(own_d);
 
-        Act dirT[1][NT];
-        if constexpr (Net::kNeedsDir) {
+        // view direction = raw rays_d (train.py:225); encoded on demand inside the network walk
+        auto dirT = [&](Act (&dt)[1][NT]) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 Act t1[pe_tiles(LD)];
-                encode3<Mode, LD>(d[n], h, t1);          // view direction = raw rays_d (train.py:225)
-                dirT[0][n] = t1[0];
+                encode3<Mode, LD>(d[n], h, t1);
+                dt[0][n] = t1[0];
             }
-        }
+        };
 
         auto z_ray = [&](int64_t ray, int s) -> float {
             if (a.z_in) return a.z_in[ray * S + s];
@@ -265,20 +265,24 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
 
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         int64_t sid[NT];
-        Act dirT[1][NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int64_t r = tile * TILE + wave * (32 * NT) + 32 * n + c;
             sid[n] = r < P.n ? r : P.n - 1;
-            if constexpr (Net::kNeedsDir) {
-                float dd[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) dd[k] = P.dir[sid[n] * 3 + k];
-                Act t1[pe_tiles(LD)];
-                encode3<Mode, LD>(dd, h, t1);
-                dirT[0][n] = t1[0];
-            }
         }
+        auto dirT = [&](Act (&dt)[1][NT]) {
+            if constexpr (Net::kNeedsDir) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    float dd[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) dd[k] = P.dir[sid[n] * 3 + k];
+                    Act t1[pe_tiles(LD)];
+                    encode3<Mode, LD>(dd, h, t1);
+                    dt[0][n] = t1[0];
+                }
+            }
+        };
         auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {

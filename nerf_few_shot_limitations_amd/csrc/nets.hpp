@@ -73,9 +73,9 @@ struct NetV1 {
     static constexpr bool kDino = false;
     // `inputs(w0, w1, x)` fills the first layer's operand tiles (the encoder lives with the caller: fused
     // renderer = from the ray, staged forward = from memory); w0/w1 are only meaningful for NetV3
-    template <class P, class Inputs>
+    template <class P, class Inputs, class Dirs>
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
-                                                Inputs&& inputs, const Act (&)[1][NT], float (&out4)[NT][4]) {
+                                                Inputs&& inputs, Dirs&&, float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
         {
             Act enc[KT0][NT];
@@ -117,9 +117,11 @@ struct NetV2 {
     typedef typename Mode::Act Act;
 
     // density_head, feature_head, colour layers; X = trunk output, Y = scratch of the same shape
-    template <class P>
+    // `dir(tile)` builds the direction-encoding tile only now, right before the colour branch needs it: its
+    // registers are not held across the trunk
+    template <class P, class Dirs>
     __device__ static __forceinline__ void tail(P& pipe, const NRF_LDS float* bias, int h, const Act (&X)[HT][NT],
-                                                Act (&Y)[HT][NT], const Act (&dir)[1][NT], float (&out4)[NT][4]) {
+                                                Act (&Y)[HT][NT], Dirs&& dir, float (&out4)[NT][4]) {
         {   // keep only the density scalar alive across the colour branch, not its 16-register tile
             f32x16 dens[NT];
             dense_head<Mode, HT, NT>(pipe, bias, h, X, dens);
@@ -132,8 +134,12 @@ struct NetV2 {
         for (int t = 0; t < HT; ++t)
 #pragma unroll
             for (int n = 0; n < NT; ++n) in9[t][n] = Y[t][n];
+        {
+            Act dt[1][NT];
+            dir(dt);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) in9[HT][n] = dir[0][n];
+            for (int n = 0; n < NT; ++n) in9[HT][n] = dt[0][n];
+        }
         Act c0[HT / 2][NT], c1[HT / 4][NT];
         dense_act<Mode, HT + 1, HT / 2, NT, true>(pipe, bias + 32 + 32 * HT, h, in9, c0);
         dense_act<Mode, HT / 2, HT / 4, NT, true>(pipe, bias + 32 + 32 * HT + 16 * HT, h, c0, c1);
@@ -145,9 +151,9 @@ struct NetV2 {
         }
     }
 
-    template <class P, class Inputs>
+    template <class P, class Inputs, class Dirs>
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
-                                                Inputs&& inputs, const Act (&dir)[1][NT], float (&out4)[NT][4]) {
+                                                Inputs&& inputs, Dirs&& dir, float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
         {
             Act enc[KT0][NT];
@@ -189,9 +195,9 @@ struct NetV3 {
     static constexpr bool kDino = true;
     typedef typename Mode::Act Act;
 
-    template <class P, class Inputs>
+    template <class P, class Inputs, class Dirs>
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
-                                                Inputs&& inputs, const Act (&dir)[1][NT], float (&out4)[NT][4]) {
+                                                Inputs&& inputs, Dirs&& dir, float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
         float w0[NT], w1[NT];
 #pragma unroll

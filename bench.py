@@ -201,6 +201,7 @@ def main():
                                                           f"torch fp32 CPU, chunk 2048 rays, best of 3"}
         rgb_b, depth_b = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, ert_eps=args.ert, device=dev, dino=dino)
         rgb32, depth32 = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f32", device=dev, dino=dino)
+        rgb16, _ = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f16", device=dev, dino=dino)
         torch.cuda.synchronize()
         # PSNR delta against a common ground truth (the lego images are not available offline: SURVEY.md section 8d):
         # GT = the same rows marched with twice the samples by the CPU oracle; both renderers at S samples vs that GT
@@ -211,6 +212,7 @@ def main():
             "psnr_oracle_vs_gt_db": round(ps_ref, 3),
             f"psnr_delta_{args.mode}_db": round(abs(O.psnr(rgb_b.cpu(), gt) - ps_ref), 4),
             "psnr_delta_f32_db": round(abs(O.psnr(rgb32.cpu(), gt) - ps_ref), 6),
+            "psnr_delta_f16_db": round(abs(O.psnr(rgb16.cpu(), gt) - ps_ref), 4),
             f"{args.mode}_max_abs_rgb": float((rgb_b.cpu() - ref["rgb"]).abs().max()),
             f"{args.mode}_max_abs_depth": float((depth_b.cpu() - ref["depth"]).abs().max()),
             f"{args.mode}_psnr_vs_oracle_db": round(O.psnr(rgb_b.cpu(), ref["rgb"]), 2),

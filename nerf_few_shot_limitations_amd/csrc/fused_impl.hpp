@@ -352,10 +352,13 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
 // ---------------------------------------------------------------------------------------------
 namespace {
 
+// the >64 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (kernel, device)
 template <class K>
-int prepare(K kernel, std::string& err) {
+int prepare(K kernel, int device, unsigned char (&done)[64], std::string& err) {
+    if (device >= 0 && device < 64 && done[device]) return NRF_OK;
     const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
     if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return NRF_EHIP; }
+    if (device >= 0 && device < 64) done[device] = 1;
     return NRF_OK;
 }
 
@@ -370,7 +373,8 @@ NetArgs net_args(const DeviceNet& net, int mode) {
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
 int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
     auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD, ERT>;
-    static int prepared = prepare(kernel, err);
+    static unsigned char done[64] = {};
+    const int prepared = prepare(kernel, net.device, done, err);
     if (prepared != NRF_OK) return prepared;
     RenderKArgs k;
     k.net = net_args(net, mode);
@@ -393,7 +397,8 @@ int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t 
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_forward(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) {
     auto kernel = forward_kernel<Net, Mode, NT, WAVES, LP, LD>;
-    static int prepared = prepare(kernel, err);
+    static unsigned char done[64] = {};
+    const int prepared = prepare(kernel, net.device, done, err);
     if (prepared != NRF_OK) return prepared;
     k.net = net_args(net, mode);
     constexpr int TILE = WAVES * 32 * NT;

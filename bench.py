@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--samples", type=int, default=64)
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--net", default="v1", choices=["v1", "v2", "v3"])
-    ap.add_argument("--scene", default="solid", choices=["fog", "solid"])
+    ap.add_argument("--scene", default="solid", choices=["fog", "solid", "smooth"])
     ap.add_argument("--ert", type=float, default=0.0)
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per pixel tile; 0 = largest <= 16 that deals the tiles evenly")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")

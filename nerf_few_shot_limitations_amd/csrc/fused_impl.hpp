@@ -166,6 +166,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 
             // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
             auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+                if constexpr (ERT) if (pipe.skip) return;     // terminated wave: its layers are skipped too, nothing reads x
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     float p[3];
@@ -211,14 +212,16 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                 // leaves the sample loop once all of its waves have
                 const int wave_dead = __all((!own_valid) || (comp.T < a.ert_eps));
                 pipe.skip = (uint32_t)__builtin_amdgcn_readfirstlane(wave_dead ? 1 : 0);   // provably wave-uniform: scalar branch
-                if (lane == 0) flags[(s & 1) * WAVES + wave] = wave_dead;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                const NRF_LDS int* fl = flags + (s & 1) * WAVES;
-                int all_dead = 1;
+                if ((s & 3) == 3) {       // the workgroup-wide vote (LDS flag + barrier) only every fourth step
+                    if (lane == 0) flags[((s >> 2) & 1) * WAVES + wave] = wave_dead;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    const NRF_LDS int* fl = flags + ((s >> 2) & 1) * WAVES;
+                    int all_dead = 1;
 #pragma unroll
-                for (int wv = 0; wv < WAVES; ++wv) all_dead &= fl[wv];
-                if (all_dead) { ++s; break; }
+                    for (int wv = 0; wv < WAVES; ++wv) all_dead &= fl[wv];
+                    if (all_dead) { ++s; break; }
+                }
             }
         }
         if (own_valid) {

@@ -454,7 +454,10 @@ def make_weights(variant: str, seed: int = 0, scene: str = "fog", **kw) -> Dict[
     scene 'fog'  : density head bias +0.25 -> thin participating medium, no ray saturates
                    (the ERT-off roofline case);
     scene 'solid': density head weight x40 and bias +1.5 -> a sizeable share of rays saturate
-                   early (the early-ray-termination case).
+                   early, but at unrelated depths from ray to ray (a random field).
+    scene 'smooth': 'solid' with the first layer blind to encoding frequencies >= 2^2 -> a low-frequency field
+                   with large coherent opaque regions, where neighbouring rays terminate together: the
+                   early-ray-termination case (wave-level skipping only pays on coherent scenes).
     """
     p = {}
     for i, (name, o, n_in) in enumerate(layer_shapes(variant, **kw)):
@@ -465,9 +468,15 @@ def make_weights(variant: str, seed: int = 0, scene: str = "fog", **kw) -> Dict[
     dens = "sigma_out" if variant == "v1" else "density_mlp.density_head"
     col = "rgb_out" if variant == "v1" else "color_mlp.color_layers.4"
     p[col + ".weight"] = p[col + ".weight"] * 6.0
-    if scene == "solid":
+    if scene in ("solid", "smooth"):
         p[dens + ".weight"] = p[dens + ".weight"] * 40.0
         p[dens + ".bias"] = p[dens + ".bias"] + 1.5
+        if scene == "smooth":
+            p[dens + ".bias"] = p[dens + ".bias"] + 5.0             # opaque: rays die after ~37 of 64 samples on average
+            first = {"v1": "layers.0", "v2": "density_mlp.density_layers.0", "v3": "dino_fusion.fusion.0"}[variant]
+            w = p[first + ".weight"].clone()
+            w[:, 3 + 6 * 2: 3 + 6 * (12 if variant == "v3" else 10)] = 0.0        # sin/cos columns of frequencies 2^2 .. 2^(L-1)
+            p[first + ".weight"] = w
     elif scene == "fog":
         p[dens + ".bias"] = p[dens + ".bias"] + 0.25
     else:

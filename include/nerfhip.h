@@ -190,6 +190,9 @@ int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear
 /* ---- misc ------------------------------------------------------------------ */
 const char* nrf_last_error(void);
 int nrf_abi_version(void);
+/* sizeof() of the ABI structs as this library was compiled (0: nrf_arch, 1: nrf_linear, 2: nrf_dino,
+ * 3: nrf_render_opts; -1 otherwise): lets a binding check its struct declarations before the first call. */
+int nrf_abi_sizeof(int which);
 /* name / average duration bookkeeping is the caller's business: the library never times anything. */
 
 #ifdef __cplusplus

@@ -51,6 +51,7 @@ class nrf_render_opts(C.Structure):
 SIGNATURES = {
     "nrf_abi_version": (C.c_int, []),
     "nrf_last_error": (C.c_char_p, []),
+    "nrf_abi_sizeof": (C.c_int, [C.c_int]),
     "nrf_model_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int]),
     "nrf_model_update": (C.c_int, [C.c_void_p, C.POINTER(nrf_linear), C.c_int, C.c_void_p]),
     "nrf_model_destroy": (None, [C.c_void_p]),
@@ -95,6 +96,9 @@ def lib() -> C.CDLL:
                 fn.restype, fn.argtypes = res, args
             if handle.nrf_abi_version() != 1:
                 raise RuntimeError("libnerfhip.so ABI version mismatch")
+            for which, st in enumerate((nrf_arch, nrf_linear, nrf_dino, nrf_render_opts)):
+                if handle.nrf_abi_sizeof(which) != C.sizeof(st):
+                    raise RuntimeError(f"libnerfhip.so: sizeof({st.__name__}) differs from the ctypes declaration")
             _lib = handle
     return _lib
 

@@ -138,6 +138,16 @@ extern "C" {
 
 int nrf_abi_version(void) { return NRF_ABI_VERSION; }
 
+int nrf_abi_sizeof(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(nrf_arch);
+        case 1: return (int)sizeof(nrf_linear);
+        case 2: return (int)sizeof(nrf_dino);
+        case 3: return (int)sizeof(nrf_render_opts);
+        default: return -1;
+    }
+}
+
 const char* nrf_last_error(void) { return g_err.c_str(); }
 
 int nrf_model_create(nrf_model** out, int device, const nrf_arch* arch, const nrf_linear* linears, int n_linear) {

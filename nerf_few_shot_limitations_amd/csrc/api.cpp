@@ -92,6 +92,7 @@ struct nrf_model {
     std::vector<float> h_bias;
     void* d_stream[3] = {nullptr, nullptr, nullptr};
     float* d_bias = nullptr;
+    unsigned long long* d_queues = nullptr;
     nrf::DeviceNet net{};
 };
 
@@ -108,6 +109,10 @@ int upload(nrf_model* m, hipStream_t s, bool allocate) {
     }
     m->h_bias = nrf::pack_bias(m->plan, m->lin);
     if (allocate) NRF_HIP(hipMalloc((void**)&m->d_bias, m->h_bias.size() * sizeof(float)));
+    if (allocate) {
+        NRF_HIP(hipMalloc((void**)&m->d_queues, nrf::kQueueSlots * sizeof(unsigned long long)));
+        m->net.queues = m->d_queues;
+    }
     NRF_HIP(hipMemcpyAsync(m->d_bias, m->h_bias.data(), m->h_bias.size() * sizeof(float), hipMemcpyHostToDevice, s));
     NRF_HIP(hipStreamSynchronize(s));     // pageable staging: the host vectors may be re-packed right after
     m->net.bias = m->d_bias;
@@ -198,6 +203,7 @@ void nrf_model_destroy(nrf_model* m) {
     for (int i = 0; i < 3; ++i)
         if (m->d_stream[i]) (void)hipFree(m->d_stream[i]);
     if (m->d_bias) (void)hipFree(m->d_bias);
+    if (m->d_queues) (void)hipFree(m->d_queues);
     delete m;
 }
 

@@ -8,6 +8,7 @@
 // (lane (c,h) owns ray 32h+c of the wave) and a whole workgroup stops marching a tile as soon as
 // every one of its rays has T < ert_eps.
 #pragma once
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -17,7 +18,7 @@ namespace nrf {
 
 constexpr int kBiasMaxFloats = 4096;                                   // 16 KiB bias table
 constexpr int kLdsRing = kSlots * kChunkBytes;                         // 128 KiB
-constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64;          // + ERT flags
+constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64 + 4096;   // + ERT flags + depth-ladder cache (ray-queue kernel)
 
 struct NetArgs {
     const void* stream;
@@ -245,6 +246,195 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused renderer with per-ray early termination: persistent lanes fed from a ray queue
+// ---------------------------------------------------------------------------------------------
+// When ert_eps > 0 the marching is no longer tile-synchronous.  Every lane pair (c, c+32) holds ONE ray and its own
+// sample index; each MLP pass advances every live ray by one sample; a ray that has used its S samples or whose
+// transmittance fell below ert_eps is written out and its lane pair takes the next ray of the wave's strip.  Strips
+// (kStrip consecutive ray ids) come from one device-wide atomic counter, so workgroups drain the frame together.
+// Both lanes of a pair run the identical compositor (the head tile carries [r,g,b,sigma] for both halves), so they
+// agree on termination without exchanging anything; only the low lane stores.  Per-ray arithmetic is exactly that of
+// render_kernel, so with ert_eps -> 0 the image is the same; with ert_eps > 0 each ray stops at ITS OWN T < eps.
+constexpr int kStrip = 128;
+constexpr int kLadderLds = 1024;      // depth-ladder entries cached in LDS (per-lane sample indices gather from it)
+
+template <class Net, class Mode, int WAVES, int LP, int LD>
+__global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKArgs P) {
+    constexpr int NT = 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NRF_LDS char* lds = (NRF_LDS char*)smem;
+    NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
+    NRF_LDS int* flags = (NRF_LDS int*)(bias + kBiasMaxFloats);
+    NRF_LDS float* zl = (NRF_LDS float*)(flags + 16);
+    typedef typename Mode::Act Act;
+    constexpr int KT0 = pe_tiles(LP);
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const RenderArgs& a = P.a;
+    const int S = a.n_samples;
+    const bool table = a.z_ladder != nullptr;             // host guarantees S <= kLadderLds then
+    if (table)
+        for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder[i];
+    load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
+
+    Pipe<WAVES, true> pipe;
+    pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
+    pipe.start();
+
+    const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, nullptr);
+    auto z_base = [&](int s) -> float { return table ? zl[s] : ladder_z(lad, s); };
+    auto z_of = [&](int64_t ray, int s) -> float {
+        if (a.z_in) return a.z_in[ray * S + s];
+        if (!a.perturb) return z_base(s);
+        float u;
+        if (a.t_rand) {
+            u = a.t_rand[ray * S + s];
+        } else {
+            int ci;
+            const int64_t g = global_ray(a, ray, ci);
+            u = counter_uniform(a.seed + (uint64_t)ci * 0x51ED27ull, (uint64_t)g, (uint32_t)s);
+        }
+        const float zc = z_base(s);
+        const float lower = s > 0 ? __fmul_rn(0.5f, __fadd_rn(zc, z_base(s - 1))) : zc;
+        const float upper = s < S - 1 ? __fmul_rn(0.5f, __fadd_rn(z_base(s + 1), zc)) : zc;
+        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));
+    };
+
+    // per-lane ray state (identical in both lanes of a pair)
+    int64_t ray = -1;
+    int s = 0;
+    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, -1.f};
+    float norm = 1.0f, zc = 1.0f;
+    Composite comp;
+    comp.reset();
+    // wave-uniform queue state
+    int64_t pool_next = 0, pool_end = 0;
+    bool exhausted = false;
+
+    for (int pass = 0;; ++pass) {
+        // ---- hand new rays to idle lane pairs -------------------------------------------------
+        if (!pipe.skip) {
+            const bool need = ray < 0;
+            const uint32_t m = (uint32_t)(__ballot(need) & 0xFFFFFFFFull);          // pairs are identical: low half suffices
+            const int cnt = __builtin_popcount(m);
+            if (cnt > 0 && !exhausted) {
+                if (pool_next == pool_end) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(a.queue, (unsigned long long)kStrip);
+                    base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((unsigned)base);
+                    if ((int64_t)base >= a.n_rays) {
+                        exhausted = true;
+                    } else {
+                        pool_next = (int64_t)base;
+                        pool_end = (int64_t)base + kStrip < a.n_rays ? (int64_t)base + kStrip : a.n_rays;
+                    }
+                }
+                if (pool_next < pool_end) {
+                    const int64_t idx = pool_next + __builtin_popcount(m & ((1u << c) - 1u));
+                    if (need && idx < pool_end) {
+                        ray = idx;
+                        s = 0;
+                        comp.reset();
+                        if (a.camera_mode) {
+                            int ci;
+                            const int64_t g = global_ray(a, ray, ci);
+                            camera_ray(a.cams[ci], g, o, d);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[ray * 3 + k]; d[k] = a.rays_d[ray * 3 + k]; }
+                        }
+                        norm = ray_norm(d);
+                        zc = z_of(ray, 0);
+                    }
+                    pool_next = pool_next + cnt < pool_end ? pool_next + cnt : pool_end;
+                }
+            }
+            // nothing left to do for this wave: keep the stream protocol, skip the math
+            const int run_dry = (exhausted && pool_next == pool_end && !__any(ray >= 0)) ? 1 : 0;
+            pipe.skip = (uint32_t)__builtin_amdgcn_readfirstlane(run_dry);     // provably wave-uniform: scalar branches only
+        }
+        const bool live = ray >= 0;
+
+        // ---- one sample per live ray ----------------------------------------------------------
+        auto dirT = [&](Act (&dt)[1][NT]) {
+            Act t1[pe_tiles(LD)];
+            encode3<Mode, LD>(d, h, t1);
+            dt[0][0] = t1[0];
+        };
+        auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+            if (pipe.skip) return;
+            float p[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = point_on_ray(o[k], d[k], zc);
+            Act e1[KT0];
+            encode3<Mode, LP>(p, h, e1, w0[0]);
+#pragma unroll
+            for (int t = 0; t < KT0; ++t) x[t][0] = e1[t];
+            if constexpr (Net::kDino) {
+                constexpr int DT = Net::KT0 - KT0;
+                const DinoTaps tp = dino_taps(a.dino, p);
+                Act dt[DT];
+                dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[0], dt);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) x[KT0 + t][0] = dt[t];
+            }
+        };
+        float out4[NT][4];
+        Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
+
+        if (!pipe.skip && live) {
+            const bool last = (s + 1 == S);
+            const float zn = last ? 0.0f : z_of(ray, s + 1);
+            const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
+            const float w = comp.template add<Mode::FAST_EXP>(out4[0][3], sigmoid_sel<Mode::FAST_EXP>(out4[0][0]),
+                                                              sigmoid_sel<Mode::FAST_EXP>(out4[0][1]), sigmoid_sel<Mode::FAST_EXP>(out4[0][2]), zc, dist);
+            if (h == 0) {
+                if (a.weights) a.weights[ray * S + s] = w;
+                if (a.z_vals) a.z_vals[ray * S + s] = zc;
+            }
+            const bool fin = last || comp.T < a.ert_eps;
+            if (fin) {
+                if (h == 0) {
+                    // samples skipped by early termination carry weight < ert_eps: report 0 and their depths
+                    for (int s2 = s + 1; s2 < S; ++s2) {
+                        if (a.weights) a.weights[ray * S + s2] = 0.0f;
+                        if (a.z_vals) a.z_vals[ray * S + s2] = z_of(ray, s2);
+                    }
+                    float r = comp.r, g = comp.g, b = comp.b;
+                    if (a.white_bkgd) {
+                        const float bg = __fsub_rn(1.0f, comp.acc);
+                        r = __fadd_rn(r, bg); g = __fadd_rn(g, bg); b = __fadd_rn(b, bg);
+                    }
+                    a.rgb[ray * 3 + 0] = r;
+                    a.rgb[ray * 3 + 1] = g;
+                    a.rgb[ray * 3 + 2] = b;
+                    a.depth[ray] = comp.depth;
+                }
+                ray = -1;
+            } else {
+                zc = zn;
+                ++s;
+            }
+        }
+
+        // ---- workgroup-wide vote every fourth pass: leave once every wave has run dry -----------
+        if ((pass & 3) == 3) {
+            if (lane == 0) flags[((pass >> 2) & 1) * WAVES + wave] = (int)pipe.skip;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const NRF_LDS int* fl = flags + ((pass >> 2) & 1) * WAVES;
+            int all_done = 1;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) all_done &= fl[wv];
+            if (all_done) break;
+        }
+    }
+    pipe.drain();
+}
+
+// ---------------------------------------------------------------------------------------------
 // staged MLP forward on explicit per-sample inputs (NeRFMLP.forward drop-in)
 // ---------------------------------------------------------------------------------------------
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
@@ -391,9 +581,41 @@ int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_
     return NRF_OK;
 }
 
+template <class Net, class Mode, int WAVES, int LP, int LD>
+int run_render_queue(const DeviceNet& net, int mode, RenderArgs a, hipStream_t s, std::string& err) {
+    auto kernel = render_queue_kernel<Net, Mode, WAVES, LP, LD>;
+    static unsigned char done[64] = {};
+    const int prepared = prepare(kernel, net.device, done, err);
+    if (prepared != NRF_OK) return prepared;
+    static std::atomic<unsigned> turn{0};
+    a.queue = net.queues + (turn.fetch_add(1) % kQueueSlots);
+    hipError_t e = hipMemsetAsync(a.queue, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) { err = std::string("queue reset: ") + hipGetErrorString(e); return NRF_EHIP; }
+    RenderKArgs k;
+    k.net = net_args(net, mode);
+    k.a = a;
+    k.n_tiles = 0;
+    const int64_t strips = (a.n_rays + kStrip - 1) / kStrip;
+    const int64_t blocks = (strips + WAVES - 1) / WAVES;
+    const int64_t grid = blocks < net.cu_count ? blocks : net.cu_count;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
+    e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("render (ray queue) launch: ") + hipGetErrorString(e); return NRF_EHIP; }
+    return NRF_OK;
+}
+
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
-    if (a.ert_eps > 0.0f) return run_render_v<Net, Mode, NT, WAVES, LP, LD, true>(net, mode, a, s, err);
+    if (a.ert_eps > 0.0f) {
+        // per-ray early termination on the ray-queue kernel (one ray per lane pair); the tile-synchronous ERT build
+        // remains for the 4x2 geometry and for depth ladders too long for the LDS cache
+        static const bool tile_ert = [] { const char* e = getenv("NRF_ERT"); return e && std::string(e) == "tile"; }();
+        if constexpr (NT == 1) {
+            if (!tile_ert && net.queues && (!a.z_ladder || a.n_samples <= kLadderLds))
+                return run_render_queue<Net, Mode, WAVES, LP, LD>(net, mode, a, s, err);
+        }
+        return run_render_v<Net, Mode, NT, WAVES, LP, LD, true>(net, mode, a, s, err);
+    }
     return run_render_v<Net, Mode, NT, WAVES, LP, LD, false>(net, mode, a, s, err);
 }
 

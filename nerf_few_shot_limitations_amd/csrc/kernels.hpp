@@ -22,7 +22,10 @@ struct DeviceNet {
     int64_t flops_per_sample;
     int device;
     int cu_count;
+    unsigned long long* queues;   // kQueueSlots counters; launches cycle through them
 };
+
+constexpr int kQueueSlots = 64;
 
 struct DinoDev {                // V3 side channel, by value in the kernel arguments
     const float* features;
@@ -60,6 +63,7 @@ struct RenderArgs {
     float* weights;
     float* z_vals;
     DinoDev dino;
+    unsigned long long* queue;   // ERT (ray-queue) kernel: device counter of rays handed out, zeroed before the launch
 };
 
 int launch_render(const DeviceNet& net, int mma_mode, const RenderArgs& a, hipStream_t s, std::string& err);

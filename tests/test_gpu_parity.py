@@ -394,6 +394,47 @@ def test_early_ray_termination_bounds(N):
     assert torch.all(out["z_vals"][:, 1:] > out["z_vals"][:, :-1])
 
 
+@pytest.mark.parametrize("variant", ["v1", "v2"])
+def test_ray_queue_kernel_matches_tile_kernel(N, variant):
+    """ert_eps > 0 selects the persistent-lane / ray-queue kernel (per-ray termination).  With a vanishing eps no ray
+    stops early, so it must reproduce the tile-synchronous kernel: same per-ray arithmetic, whatever lane a ray lands on.
+    Ragged ray counts, explicit rays + weights/z outputs, camera mode, and the fp32 geometry (4 waves) are covered."""
+    mk = model_v1 if variant == "v1" else model_v2
+    c2w = T(O.LEGO_LIKE_C2W)
+    for mode in ("bf16", "f32"):
+        m, _ = mk(N, "solid", mode)
+        for (H, W, S) in ((37, 53, 16), (8, 9, 40)):
+            ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
+            a = N.render_rays(m, ro, rd, 2.0, 6.0, S, return_z=True)
+            b = N.render_rays(m, ro, rd, 2.0, 6.0, S, return_z=True, ert_eps=1e-37)
+            assert maxdiff(a["rgb"], b["rgb"]) <= 1e-30 and maxdiff(a["depth"], b["depth"]) <= 1e-30
+            assert maxdiff(a["weights"], b["weights"]) <= 1e-30 and torch.equal(a["z_vals"], b["z_vals"])
+            cam = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ert_eps=1e-37)
+            assert maxdiff(cam[0], a["rgb"]) <= 1e-30
+        # jittered sampling through the queue kernel: explicit t_rand and the counter RNG
+        H, W, S = 12, 16, 24
+        ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
+        tr = torch.from_numpy(O.uniform01(5, H * W * S).reshape(H * W, S))
+        a = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=tr)
+        b = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=tr, ert_eps=1e-37)
+        assert maxdiff(a["rgb"], b["rgb"]) <= 1e-30
+        a = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, perturb=True, seed=3)
+        b = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, perturb=True, seed=3, ert_eps=1e-37)
+        assert maxdiff(a[0], b[0]) <= 1e-30
+
+
+def test_per_ray_termination_bound(N):
+    """Each ray stops at its own T < eps: the image differs from the full march by < eps (rgb) / eps*far (depth)."""
+    H = W = 48; S = 64
+    c2w = T(O.LEGO_LIKE_C2W)
+    for scene in ("solid", "smooth"):
+        m, _ = model_v1(N, scene, "bf16")
+        full = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
+        for eps in (1e-2, 1e-4):
+            ert = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ert_eps=eps)
+            assert maxdiff(ert[0], full[0]) <= eps * 1.01 and maxdiff(ert[1], full[1]) <= eps * 6.0 * 1.01
+
+
 def test_early_termination_wave_skip_on_an_opaque_wall(N):
     """A scene where whole waves terminate: sigma = +40 everywhere (bias-only head) -> every ray is opaque after the
     first samples; with ert_eps the waves stop computing, the result stays within eps of the full march, and

@@ -19,6 +19,8 @@ namespace nrf {
 constexpr int kBiasMaxFloats = 4096;                                   // 16 KiB bias table
 constexpr int kLdsRing = kSlots * kChunkBytes;                         // 128 KiB
 constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64 + 4096;   // + ERT flags + depth-ladder cache (ray-queue kernel)
+constexpr int kLdsBytesQueue = kLdsBytes + 14 * 512 * 4;                // + per-lane ray state of the ray-queue kernel
+static_assert(kLdsBytesQueue <= 160 * 1024, "ray-queue kernel: LDS over budget (use a 6-slot ring)");
 
 struct NetArgs {
     const void* stream;
@@ -266,6 +268,13 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
     NRF_LDS int* flags = (NRF_LDS int*)(bias + kBiasMaxFloats);
     NRF_LDS float* zl = (NRF_LDS float*)(flags + 16);
+    // Per-lane ray state lives in LDS ([field][thread]: lane-linear, conflict-free) and is only pulled into registers
+    // around the few instructions that use it: nothing per-ray is live across the MLP, whose register budget is full
+    // (a compiler spill to scratch there is a VMEM op whose wait drains the LDS-DMA weight queue).
+    NRF_LDS float* st = zl + kLadderLds;
+    enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_NORM, F_Z, F_T, F_R, F_G, F_B, F_DEPTH, F_ACC, kFields };
+    const int nthreads = WAVES * 64;
+    auto ST = [&](int f) -> NRF_LDS float& { return st[f * nthreads + threadIdx.x]; };
     typedef typename Mode::Act Act;
     constexpr int KT0 = pe_tiles(LP);
 
@@ -276,6 +285,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     const bool table = a.z_ladder != nullptr;             // host guarantees S <= kLadderLds then
     if (table)
         for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder[i];
+    ST(F_OX) = 0.f; ST(F_OY) = 0.f; ST(F_OZ) = 0.f; ST(F_DX) = 0.f; ST(F_DY) = 0.f; ST(F_DZ) = -1.f; ST(F_Z) = 1.f;
     load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
 
     Pipe<WAVES, true> pipe;
@@ -301,13 +311,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
         return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));
     };
 
-    // per-lane ray state (identical in both lanes of a pair)
-    int64_t ray = -1;
+    // registers: only the ray id and its sample index (identical in both lanes of a pair)
+    int ray = -1;
     int s = 0;
-    float o[3] = {0.f, 0.f, 0.f}, d[3] = {0.f, 0.f, -1.f};
-    float norm = 1.0f, zc = 1.0f;
-    Composite comp;
-    comp.reset();
     // wave-uniform queue state
     int64_t pool_next = 0, pool_end = 0;
     bool exhausted = false;
@@ -334,19 +340,22 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
                 if (pool_next < pool_end) {
                     const int64_t idx = pool_next + __builtin_popcount(m & ((1u << c) - 1u));
                     if (need && idx < pool_end) {
-                        ray = idx;
+                        ray = (int)idx;
                         s = 0;
-                        comp.reset();
+                        float o[3], d[3];
                         if (a.camera_mode) {
                             int ci;
-                            const int64_t g = global_ray(a, ray, ci);
+                            const int64_t g = global_ray(a, idx, ci);
                             camera_ray(a.cams[ci], g, o, d);
                         } else {
 #pragma unroll
-                            for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[ray * 3 + k]; d[k] = a.rays_d[ray * 3 + k]; }
+                            for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[idx * 3 + k]; d[k] = a.rays_d[idx * 3 + k]; }
                         }
-                        norm = ray_norm(d);
-                        zc = z_of(ray, 0);
+                        ST(F_OX) = o[0]; ST(F_OY) = o[1]; ST(F_OZ) = o[2];
+                        ST(F_DX) = d[0]; ST(F_DY) = d[1]; ST(F_DZ) = d[2];
+                        ST(F_NORM) = ray_norm(d);
+                        ST(F_Z) = z_of(idx, 0);
+                        ST(F_T) = 1.0f; ST(F_R) = 0.0f; ST(F_G) = 0.0f; ST(F_B) = 0.0f; ST(F_DEPTH) = 0.0f; ST(F_ACC) = 0.0f;
                     }
                     pool_next = pool_next + cnt < pool_end ? pool_next + cnt : pool_end;
                 }
@@ -355,19 +364,21 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
             const int run_dry = (exhausted && pool_next == pool_end && !__any(ray >= 0)) ? 1 : 0;
             pipe.skip = (uint32_t)__builtin_amdgcn_readfirstlane(run_dry);     // provably wave-uniform: scalar branches only
         }
-        const bool live = ray >= 0;
 
         // ---- one sample per live ray ----------------------------------------------------------
         auto dirT = [&](Act (&dt)[1][NT]) {
+            const float d[3] = {ST(F_DX), ST(F_DY), ST(F_DZ)};
             Act t1[pe_tiles(LD)];
             encode3<Mode, LD>(d, h, t1);
             dt[0][0] = t1[0];
         };
         auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
             if (pipe.skip) return;
+            const float zc = ST(F_Z);
             float p[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) p[k] = point_on_ray(o[k], d[k], zc);
+            p[0] = point_on_ray(ST(F_OX), ST(F_DX), zc);
+            p[1] = point_on_ray(ST(F_OY), ST(F_DY), zc);
+            p[2] = point_on_ray(ST(F_OZ), ST(F_DZ), zc);
             Act e1[KT0];
             encode3<Mode, LP>(p, h, e1, w0[0]);
 #pragma unroll
@@ -384,37 +395,43 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
         float out4[NT][4];
         Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
 
-        if (!pipe.skip && live) {
+        if (!pipe.skip && ray >= 0) {
             const bool last = (s + 1 == S);
+            const float zc = ST(F_Z);
+            const float norm = ST(F_NORM);
             const float zn = last ? 0.0f : z_of(ray, s + 1);
             const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
+            Composite comp;
+            comp.T = ST(F_T); comp.r = ST(F_R); comp.g = ST(F_G); comp.b = ST(F_B); comp.depth = ST(F_DEPTH); comp.acc = ST(F_ACC);
             const float w = comp.template add<Mode::FAST_EXP>(out4[0][3], sigmoid_sel<Mode::FAST_EXP>(out4[0][0]),
                                                               sigmoid_sel<Mode::FAST_EXP>(out4[0][1]), sigmoid_sel<Mode::FAST_EXP>(out4[0][2]), zc, dist);
+            const int64_t rr = ray;
             if (h == 0) {
-                if (a.weights) a.weights[ray * S + s] = w;
-                if (a.z_vals) a.z_vals[ray * S + s] = zc;
+                if (a.weights) a.weights[rr * S + s] = w;
+                if (a.z_vals) a.z_vals[rr * S + s] = zc;
             }
             const bool fin = last || comp.T < a.ert_eps;
             if (fin) {
                 if (h == 0) {
                     // samples skipped by early termination carry weight < ert_eps: report 0 and their depths
                     for (int s2 = s + 1; s2 < S; ++s2) {
-                        if (a.weights) a.weights[ray * S + s2] = 0.0f;
-                        if (a.z_vals) a.z_vals[ray * S + s2] = z_of(ray, s2);
+                        if (a.weights) a.weights[rr * S + s2] = 0.0f;
+                        if (a.z_vals) a.z_vals[rr * S + s2] = z_of(rr, s2);
                     }
                     float r = comp.r, g = comp.g, b = comp.b;
                     if (a.white_bkgd) {
                         const float bg = __fsub_rn(1.0f, comp.acc);
                         r = __fadd_rn(r, bg); g = __fadd_rn(g, bg); b = __fadd_rn(b, bg);
                     }
-                    a.rgb[ray * 3 + 0] = r;
-                    a.rgb[ray * 3 + 1] = g;
-                    a.rgb[ray * 3 + 2] = b;
-                    a.depth[ray] = comp.depth;
+                    a.rgb[rr * 3 + 0] = r;
+                    a.rgb[rr * 3 + 1] = g;
+                    a.rgb[rr * 3 + 2] = b;
+                    a.depth[rr] = comp.depth;
                 }
                 ray = -1;
             } else {
-                zc = zn;
+                ST(F_T) = comp.T; ST(F_R) = comp.r; ST(F_G) = comp.g; ST(F_B) = comp.b; ST(F_DEPTH) = comp.depth; ST(F_ACC) = comp.acc;
+                ST(F_Z) = zn;
                 ++s;
             }
         }
@@ -547,9 +564,9 @@ namespace {
 
 // the >64 KiB dynamic-LDS opt-in is a per-device function attribute: set it once per (kernel, device)
 template <class K>
-int prepare(K kernel, int device, unsigned char (&done)[64], std::string& err) {
+int prepare(K kernel, int device, unsigned char (&done)[64], std::string& err, int lds_bytes = kLdsBytes) {
     if (device >= 0 && device < 64 && done[device]) return NRF_OK;
-    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    const hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     if (e != hipSuccess) { err = std::string("hipFuncSetAttribute: ") + hipGetErrorString(e); return NRF_EHIP; }
     if (device >= 0 && device < 64) done[device] = 1;
     return NRF_OK;
@@ -585,7 +602,7 @@ template <class Net, class Mode, int WAVES, int LP, int LD>
 int run_render_queue(const DeviceNet& net, int mode, RenderArgs a, hipStream_t s, std::string& err) {
     auto kernel = render_queue_kernel<Net, Mode, WAVES, LP, LD>;
     static unsigned char done[64] = {};
-    const int prepared = prepare(kernel, net.device, done, err);
+    const int prepared = prepare(kernel, net.device, done, err, kLdsBytesQueue);
     if (prepared != NRF_OK) return prepared;
     static std::atomic<unsigned> turn{0};
     a.queue = net.queues + (turn.fetch_add(1) % kQueueSlots);
@@ -598,7 +615,7 @@ int run_render_queue(const DeviceNet& net, int mode, RenderArgs a, hipStream_t s
     const int64_t strips = (a.n_rays + kStrip - 1) / kStrip;
     const int64_t blocks = (strips + WAVES - 1) / WAVES;
     const int64_t grid = blocks < net.cu_count ? blocks : net.cu_count;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytesQueue, s, k);
     e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("render (ray queue) launch: ") + hipGetErrorString(e); return NRF_EHIP; }
     return NRF_OK;
@@ -611,7 +628,7 @@ int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t 
         // remains for the 4x2 geometry and for depth ladders too long for the LDS cache
         static const bool tile_ert = [] { const char* e = getenv("NRF_ERT"); return e && std::string(e) == "tile"; }();
         if constexpr (NT == 1) {
-            if (!tile_ert && net.queues && (!a.z_ladder || a.n_samples <= kLadderLds))
+            if (!tile_ert && net.queues && a.n_rays < (int64_t)1 << 31 && (!a.z_ladder || a.n_samples <= kLadderLds))
                 return run_render_queue<Net, Mode, WAVES, LP, LD>(net, mode, a, s, err);
         }
         return run_render_v<Net, Mode, NT, WAVES, LP, LD, true>(net, mode, a, s, err);

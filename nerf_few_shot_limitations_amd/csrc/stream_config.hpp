@@ -4,5 +4,5 @@
 #define NRF_CHUNK_FRAGS 16        // 1-KiB fragments per chunk (one barrier per chunk)
 #endif
 #ifndef NRF_SLOTS
-#define NRF_SLOTS 8               // LDS ring depth in chunks (NRF_CHUNK_FRAGS * NRF_SLOTS KiB)
+#define NRF_SLOTS 6               // LDS ring depth in chunks (NRF_CHUNK_FRAGS * NRF_SLOTS KiB); 6 and 8 measure the same (profiles/README.md)
 #endif

@@ -273,12 +273,19 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     // (a compiler spill to scratch there is a VMEM op whose wait drains the LDS-DMA weight queue).
     NRF_LDS float* st = zl + kLadderLds;
     enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_NORM, F_Z, F_T, F_R, F_G, F_B, F_DEPTH, F_ACC, kFields };
-    const int nthreads = WAVES * 64;
-    auto ST = [&](int f) -> NRF_LDS float& { return st[f * nthreads + threadIdx.x]; };
+    constexpr int nthreads = WAVES * 64;
+    // ONE address register for this thread's column; fields sit at immediate offsets f*nthreads*4 (< 64 KiB, the DS
+    // offset field).  The empty asm keeps the compiler from folding the (> 64 KiB) region base into 14 separate
+    // per-field address registers, which it then spilled to scratch -- every reload of those drained the LDS-DMA queue.
+    // Everything derived from the thread id is re-derived inside each pass from an opaque copy (tid_now): loop-invariant
+    // per-lane values would otherwise be hoisted, spilled at the MLP's register peak and reloaded from scratch every pass.
+    int tid_now = threadIdx.x;
+    NRF_LDS float* st_me = st + tid_now;
+    auto ST = [&](int f) -> NRF_LDS float& { return st_me[f * nthreads]; };
     typedef typename Mode::Act Act;
     constexpr int KT0 = pe_tiles(LP);
 
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const RenderArgs& a = P.a;
     const int S = a.n_samples;
@@ -319,6 +326,10 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     bool exhausted = false;
 
     for (int pass = 0;; ++pass) {
+        tid_now = threadIdx.x;
+        asm volatile("" : "+v"(tid_now));
+        lane = tid_now & 63; c = lane & 31; h = lane >> 5;
+        st_me = st + tid_now;
         // ---- hand new rays to idle lane pairs -------------------------------------------------
         if (!pipe.skip) {
             const bool need = ray < 0;

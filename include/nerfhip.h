@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 1
+#define NRF_ABI_VERSION 2
 
 /* error codes */
 #define NRF_OK            0
@@ -194,6 +194,53 @@ int nrf_abi_version(void);
  * 3: nrf_render_opts; -1 otherwise): lets a binding check its struct declarations before the first call. */
 int nrf_abi_sizeof(int which);
 /* name / average duration bookkeeping is the caller's business: the library never times anything. */
+
+/* ------------------------------------------------------------------------
+ * Training path: what loss.backward() and
+ * optimizer.step() of src/training/train.py:282-288 run through.  Built for
+ * NRF_NET_V1 (nerf_model.NeRFMLP, the network of train_minimal.py:28).
+ *
+ * Parameters and gradients travel as ONE flat fp32 device vector: the Linears
+ * in state_dict order, each weight (out_f*in_f, row-major) followed by its
+ * bias (out_f) -- nrf_param_count() floats.  The Python module keeps its
+ * nn.Parameters as views into such a vector, so torch.optim.Adam (or
+ * nrf_adam_step) updates it in place and nrf_model_update_device re-packs
+ * the MFMA operand streams from it without leaving the device.
+ * ------------------------------------------------------------------------ */
+int64_t nrf_param_count(const nrf_model* m);
+
+/* Replaces nrf_model_update for device-resident parameters: re-packs the
+ * forward (and, once training has been used, backward) streams of the modes in
+ * mode_mask (bit NRF_MMA_*) from flat_params.  Enqueued on `stream`. */
+int nrf_model_update_device(nrf_model* m, const float* flat_params, int mode_mask, void* stream);
+
+/* Bytes of saved tensors ("context") a forward_train/backward pair needs for n
+ * samples; the caller allocates it (device) and keeps it until backward ran. */
+int64_t nrf_train_context_bytes(nrf_model* m, int mma_mode, int64_t n);
+
+/* nerf_model.py:16-24 forward with grad enabled: out4 as nrf_mlp_forward_v1,
+ * and every layer's activations saved into ctx. */
+int nrf_mlp_forward_train_v1(nrf_model* m, int mma_mode, const float* x_enc, int64_t n, float* out4,
+                             void* ctx, int64_t ctx_bytes, void* stream);
+
+/* Its backward: g_out4 = dL/d out4 (n,4); flat_grad (nrf_param_count floats)
+ * += dL/d parameters.  out4 is the tensor forward_train wrote.  No gradient
+ * with respect to x_enc is produced (the reference never needs one). */
+int nrf_mlp_backward_v1(nrf_model* m, int mma_mode, const float* out4, const float* g_out4, int64_t n,
+                        void* ctx, int64_t ctx_bytes, float* flat_grad, void* stream);
+
+/* Backward of nrf_composite (autograd through nerf_mlp.py:181-212): given
+ * dL/d rgb_map (n_rays,3), optionally dL/d depth (n_rays) and dL/d weights
+ * (n_rays,S), writes dL/d rgb (strided like the inputs) and dL/d sigma. */
+int nrf_composite_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride,
+                           const float* z_vals, const float* rays_d, int64_t n_rays, int n_samples, int white_bkgd,
+                           const float* g_rgb, const float* g_depth, const float* g_weights,
+                           float* d_rgb, int d_rgb_stride, float* d_sigma, int d_sigma_stride, void* stream);
+
+/* torch.optim.Adam's update (train.py:113-118; no amsgrad) on flat vectors;
+ * step counts from 1. */
+int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
 
 #ifdef __cplusplus
 }

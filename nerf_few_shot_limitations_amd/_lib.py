@@ -74,6 +74,16 @@ SIGNATURES = {
     "nrf_debug_pack": (C.c_int, [C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "nrf_project_fetch": (C.c_int, [C.POINTER(nrf_dino), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    # training path
+    "nrf_param_count": (C.c_int64, [C.c_void_p]),
+    "nrf_model_update_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "nrf_train_context_bytes": (C.c_int64, [C.c_void_p, C.c_int, C.c_int64]),
+    "nrf_mlp_forward_train_v1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "nrf_mlp_backward_v1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "nrf_composite_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "nrf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                C.c_float, C.c_int, C.c_void_p]),
 }
 
 _lib = None
@@ -94,7 +104,7 @@ def lib() -> C.CDLL:
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(handle, name)          # AttributeError if the symbol is not exported
                 fn.restype, fn.argtypes = res, args
-            if handle.nrf_abi_version() != 1:
+            if handle.nrf_abi_version() != 2:
                 raise RuntimeError("libnerfhip.so ABI version mismatch")
             for which, st in enumerate((nrf_arch, nrf_linear, nrf_dino, nrf_render_opts)):
                 if handle.nrf_abi_sizeof(which) != C.sizeof(st):

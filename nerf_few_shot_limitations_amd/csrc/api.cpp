@@ -4,6 +4,7 @@
 // verified.  No C++ exception leaves this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -94,6 +95,19 @@ struct nrf_model {
     float* d_bias = nullptr;
     unsigned long long* d_queues = nullptr;
     nrf::DeviceNet net{};
+    // training path (built on first use: ensure_train)
+    bool train_ready = false;
+    bool lin_stale = false;                 // parameters were last set from a device vector: the host copy `lin` is old
+    bool bfresh[3] = {false, false, false}; // backward stream of the mode matches the current parameters
+    nrf::ParamLayout layout;
+    nrf::NetPlan bplan;
+    nrf::TrainPlan tplan;
+    nrf::TrainDev train{};
+    void* d_bstream[3] = {nullptr, nullptr, nullptr};
+    int32_t* d_maps = nullptr;
+    int32_t* d_src[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [forward|backward][16-bit|fp32] element sources
+    int64_t n_src[2][2] = {{0, 0}, {0, 0}};
+    int32_t* d_bias_src = nullptr;
 };
 
 namespace {
@@ -107,6 +121,15 @@ int upload(nrf_model* m, hipStream_t s, bool allocate) {
         m->net.stream[mode] = m->d_stream[mode];
         m->net.n_chunks[mode] = m->h_stream[mode].n_chunks;
     }
+    m->lin_stale = false;
+    if (m->train_ready) {
+        for (int mode = 0; mode < 3; ++mode) {
+            const nrf::PackedStream ps = nrf::pack_stream(m->bplan, m->lin, mode);
+            NRF_HIP(hipMemcpyAsync(m->d_bstream[mode], ps.bytes.data(), ps.bytes.size(), hipMemcpyHostToDevice, s));
+            NRF_HIP(hipStreamSynchronize(s));
+            m->bfresh[mode] = true;
+        }
+    }
     m->h_bias = nrf::pack_bias(m->plan, m->lin);
     if (allocate) NRF_HIP(hipMalloc((void**)&m->d_bias, m->h_bias.size() * sizeof(float)));
     if (allocate) {
@@ -118,6 +141,67 @@ int upload(nrf_model* m, hipStream_t s, bool allocate) {
     m->net.bias = m->d_bias;
     m->net.n_bias = m->plan.n_bias;
     m->net.flops_per_sample = m->plan.flops_per_sample;
+    return NRF_OK;
+}
+
+// device-side element sources of the forward streams + bias table (needed by nrf_model_update_device)
+int ensure_sources(nrf_model* m) {
+    if (m->d_src[0][0]) return NRF_OK;
+    m->layout = nrf::param_layout(m->lin);
+    for (int f32 = 0; f32 < 2; ++f32) {
+        const std::vector<int32_t> src = nrf::stream_sources(m->plan, m->layout, f32 != 0);
+        NRF_HIP(hipMalloc((void**)&m->d_src[0][f32], src.size() * sizeof(int32_t)));
+        NRF_HIP(hipMemcpy(m->d_src[0][f32], src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        m->n_src[0][f32] = (int64_t)src.size();
+    }
+    const std::vector<int32_t> bsrc = nrf::bias_sources(m->plan, m->layout);
+    NRF_HIP(hipMalloc((void**)&m->d_bias_src, bsrc.size() * sizeof(int32_t)));
+    NRF_HIP(hipMemcpy(m->d_bias_src, bsrc.data(), bsrc.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return NRF_OK;
+}
+
+// backward streams, weight-gradient maps: everything the training kernels need beyond the forward model
+int ensure_train(nrf_model* m) {
+    if (m->train_ready) return NRF_OK;
+    int rc = ensure_sources(m);
+    if (rc != NRF_OK) return rc;
+    std::string err;
+    if (!nrf::make_backward_plan(m->arch, m->lin, m->bplan, err) || !nrf::make_train_plan(m->arch, m->plan, m->layout, m->tplan, err))
+        return fail(NRF_EUNSUPPORTED, err);
+    if ((int)m->tplan.slot_tiles.size() > nrf::kMaxSlots || (int)m->tplan.jobs.size() > nrf::kMaxJobs)
+        return fail(NRF_EUNSUPPORTED, "network too deep for the training path");
+    for (int mode = 0; mode < 3; ++mode) {
+        const nrf::PackedStream ps = nrf::pack_stream(m->bplan, m->lin, mode);
+        NRF_HIP(hipMalloc(&m->d_bstream[mode], ps.bytes.size()));
+        NRF_HIP(hipMemcpy(m->d_bstream[mode], ps.bytes.data(), ps.bytes.size(), hipMemcpyHostToDevice));
+        m->train.bstream[mode] = m->d_bstream[mode];
+        m->train.n_bchunks[mode] = ps.n_chunks;
+        m->bfresh[mode] = !m->lin_stale;
+    }
+    for (int f32 = 0; f32 < 2; ++f32) {
+        const std::vector<int32_t> src = nrf::stream_sources(m->bplan, m->layout, f32 != 0);
+        NRF_HIP(hipMalloc((void**)&m->d_src[1][f32], src.size() * sizeof(int32_t)));
+        NRF_HIP(hipMemcpy(m->d_src[1][f32], src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        m->n_src[1][f32] = (int64_t)src.size();
+    }
+    const int nj = (int)m->tplan.jobs.size();
+    std::vector<int32_t> maps((size_t)nj * nrf::kMapStride, -1);
+    for (int j = 0; j < nj; ++j) {
+        const nrf::GradJobPlan& J = m->tplan.jobs[j];
+        if (J.row_w.size() > 320 || J.col.size() > 320) return fail(NRF_EUNSUPPORTED, "layer too wide for the weight-gradient maps");
+        std::copy(J.row_w.begin(), J.row_w.end(), maps.begin() + (size_t)j * nrf::kMapStride);
+        std::copy(J.row_b.begin(), J.row_b.end(), maps.begin() + (size_t)j * nrf::kMapStride + 320);
+        std::copy(J.col.begin(), J.col.end(), maps.begin() + (size_t)j * nrf::kMapStride + 640);
+        m->train.job_x_slot[j] = J.x_slot; m->train.job_dz_slot[j] = J.dz_slot; m->train.job_KT[j] = J.KT; m->train.job_MT[j] = J.MT;
+    }
+    NRF_HIP(hipMalloc((void**)&m->d_maps, maps.size() * sizeof(int32_t)));
+    NRF_HIP(hipMemcpy(m->d_maps, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    m->train.maps = m->d_maps;
+    m->train.n_jobs = nj;
+    m->train.n_slots = (int)m->tplan.slot_tiles.size();
+    for (int i = 0; i < m->train.n_slots; ++i) m->train.slot_tiles[i] = m->tplan.slot_tiles[i];
+    m->train.n_params = m->layout.total;
+    m->train_ready = true;
     return NRF_OK;
 }
 
@@ -204,6 +288,13 @@ void nrf_model_destroy(nrf_model* m) {
         if (m->d_stream[i]) (void)hipFree(m->d_stream[i]);
     if (m->d_bias) (void)hipFree(m->d_bias);
     if (m->d_queues) (void)hipFree(m->d_queues);
+    for (int i = 0; i < 3; ++i)
+        if (m->d_bstream[i]) (void)hipFree(m->d_bstream[i]);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            if (m->d_src[i][j]) (void)hipFree(m->d_src[i][j]);
+    if (m->d_maps) (void)hipFree(m->d_maps);
+    if (m->d_bias_src) (void)hipFree(m->d_bias_src);
     delete m;
 }
 
@@ -341,6 +432,104 @@ int nrf_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
     const int r = nrf::launch_composite(rgb, rgb_stride, sigma, sigma_stride, z_vals, rays_d, n_rays, n_samples, white_bkgd, out_rgb,
                                         out_depth, out_weights, (hipStream_t)stream);
     return r == NRF_OK ? NRF_OK : fail(r, "composite launch failed");
+}
+
+int64_t nrf_param_count(const nrf_model* m) {
+    if (!m) return 0;
+    int64_t n = 0;
+    for (const auto& l : m->lin) n += (int64_t)l.out_f * l.in_f + l.out_f;
+    return n;
+}
+
+int nrf_model_update_device(nrf_model* m, const float* flat_params, int mode_mask, void* stream) {
+    if (!m || !flat_params) return fail(NRF_EINVAL, "nrf_model_update_device: null argument");
+    if (mode_mask <= 0 || mode_mask > 7) return fail(NRF_EINVAL, "mode_mask must select at least one of the three modes");
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    int rc = ensure_sources(m);
+    if (rc != NRF_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    for (int mode = 0; mode < 3; ++mode) {
+        if (!(mode_mask & (1 << mode))) continue;
+        const int f32 = mode == NRF_MMA_F32;
+        rc = nrf::launch_repack(flat_params, m->d_src[0][f32], m->n_src[0][f32], mode, m->d_stream[mode], s);
+        if (rc != NRF_OK) return fail(rc, "repack launch failed");
+        if (m->train_ready) {
+            rc = nrf::launch_repack(flat_params, m->d_src[1][f32], m->n_src[1][f32], mode, m->d_bstream[mode], s);
+            if (rc != NRF_OK) return fail(rc, "repack launch failed");
+            m->bfresh[mode] = true;
+        }
+    }
+    m->lin_stale = true;
+    for (int mode = 0; mode < 3; ++mode)
+        if (!(mode_mask & (1 << mode))) m->bfresh[mode] = false;
+    rc = nrf::launch_repack(flat_params, m->d_bias_src, m->plan.n_bias, NRF_MMA_F32, m->d_bias, s);
+    return rc == NRF_OK ? NRF_OK : fail(rc, "repack launch failed");
+}
+
+int64_t nrf_train_context_bytes(nrf_model* m, int mma_mode, int64_t n) {
+    if (!m || n < 0 || mma_mode < 0 || mma_mode > 2) { (void)fail(NRF_EINVAL, "nrf_train_context_bytes: bad argument"); return -1; }
+    DeviceGuard guard(m->device);
+    if (!guard.ok) { (void)fail(NRF_EHIP, "cannot select the model's device"); return -1; }
+    if (ensure_train(m) != NRF_OK) return -1;
+    return nrf::train_ctx_bytes(m->train, mma_mode, n);
+}
+
+int nrf_mlp_forward_train_v1(nrf_model* m, int mma_mode, const float* x_enc, int64_t n, float* out4, void* ctx, int64_t ctx_bytes,
+                             void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n == 0) return NRF_OK;
+    if (!x_enc || !out4 || !ctx) return fail(NRF_EINVAL, "null pointer");
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    const int rc = ensure_train(m);
+    if (rc != NRF_OK) return rc;
+    if (ctx_bytes < nrf::train_ctx_bytes(m->train, mma_mode, n)) return fail(NRF_EINVAL, "context buffer smaller than nrf_train_context_bytes");
+    std::string err;
+    const int r = nrf::launch_train_forward(m->net, m->train, mma_mode, x_enc, n, out4, ctx, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_mlp_backward_v1(nrf_model* m, int mma_mode, const float* out4, const float* g_out4, int64_t n, void* ctx, int64_t ctx_bytes,
+                        float* flat_grad, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n == 0) return NRF_OK;
+    if (!out4 || !g_out4 || !ctx || !flat_grad) return fail(NRF_EINVAL, "null pointer");
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    const int rc = ensure_train(m);
+    if (rc != NRF_OK) return rc;
+    if (ctx_bytes < nrf::train_ctx_bytes(m->train, mma_mode, n)) return fail(NRF_EINVAL, "context buffer smaller than nrf_train_context_bytes");
+    if (!m->bfresh[mma_mode])
+        return fail(NRF_EINVAL, "backward weights of this mode are older than the parameters: call nrf_model_update_device (with this mode) first");
+    std::string err;
+    const int r = nrf::launch_train_backward(m->net, m->train, mma_mode, out4, g_out4, n, ctx, flat_grad, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_composite_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z_vals, const float* rays_d,
+                           int64_t n_rays, int n_samples, int white_bkgd, const float* g_rgb, const float* g_depth, const float* g_weights,
+                           float* d_rgb, int d_rgb_stride, float* d_sigma, int d_sigma_stride, void* stream) {
+    if (n_rays < 0 || n_samples < 1 || n_samples > 4096) return fail(NRF_EINVAL, "bad sizes");
+    if (rgb_stride < 3 || sigma_stride < 1 || d_rgb_stride < 3 || d_sigma_stride < 1) return fail(NRF_EINVAL, "bad strides");
+    if (n_rays == 0) return NRF_OK;
+    if (!rgb || !sigma || !z_vals || !rays_d || !d_rgb || !d_sigma) return fail(NRF_EINVAL, "null pointer");
+    if (!g_rgb && !g_depth && !g_weights) return fail(NRF_EINVAL, "no incoming gradient");
+    const int r = nrf::launch_composite_backward(rgb, rgb_stride, sigma, sigma_stride, z_vals, rays_d, n_rays, n_samples, white_bkgd, g_rgb,
+                                                 g_depth, g_weights, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "composite backward launch failed");
+}
+
+int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, void* stream) {
+    if (n < 0 || step < 1) return fail(NRF_EINVAL, "bad n / step");
+    if (n == 0) return NRF_OK;
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(NRF_EINVAL, "null pointer");
+    if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps >= 0.0f)) return fail(NRF_EINVAL, "bad Adam constants");
+    const int r = nrf::launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "adam launch failed");
 }
 
 int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance, const float* u,

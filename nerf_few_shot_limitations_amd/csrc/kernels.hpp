@@ -71,6 +71,35 @@ int launch_forward_v1(const DeviceNet& net, int mma_mode, const float* x_enc, in
 int launch_forward(const DeviceNet& net, int mma_mode, const float* pos, const float* dir, const float* dino, int64_t n,
                    float* rgb, float* density, hipStream_t s, std::string& err);
 
+// ---- training path (train_v1.hip) -------------------------------------------------
+constexpr int kMaxSlots = 40;
+constexpr int kMaxJobs = 20;
+constexpr int kMapStride = 3 * 320;      // per weight-gradient job: row_w[320] | row_b[320] | col[320]
+
+struct TrainDev {
+    const void* bstream[3];     // backward-chain (transposed) streams by NRF_MMA_*
+    uint32_t n_bchunks[3];
+    const int32_t* maps;        // device, n_jobs * kMapStride
+    int n_slots;
+    int slot_tiles[kMaxSlots];  // feature tiles per saved-tensor slot
+    int n_jobs;
+    int job_x_slot[kMaxJobs], job_dz_slot[kMaxJobs], job_KT[kMaxJobs], job_MT[kMaxJobs];
+    int64_t n_params;
+};
+
+int64_t train_ctx_bytes(const TrainDev& t, int mma_mode, int64_t n);
+int launch_train_forward(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* x_enc, int64_t n, float* out4, void* ctx,
+                         hipStream_t s, std::string& err);
+// dZ chain + weight gradients: grad (flat, n_params floats) += dL/dparams
+int launch_train_backward(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* out4, const float* g_out4, int64_t n,
+                          void* ctx, float* grad, hipStream_t s, std::string& err);
+int launch_repack(const float* flat, const int32_t* src, int64_t n_elems, int mma_mode, void* out, hipStream_t s);
+int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
+                hipStream_t s);
+int launch_composite_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
+                              int64_t n_rays, int S, int white_bkgd, const float* g_rgb, const float* g_depth, const float* g_w,
+                              float* d_rgb, int d_rgb_stride, float* d_sigma, int d_sigma_stride, hipStream_t s);
+
 // staged kernels (staged_kernels.hip)
 int launch_get_rays(const Camera& cam, int64_t ray_begin, int64_t n, float* rays_o, float* rays_d, hipStream_t s);
 int launch_sample(const float* rays_o, const float* rays_d, int64_t n_rays, float near, float far, int S, int lindisp,

@@ -215,45 +215,151 @@ std::vector<float> pack_bias(const NetPlan& plan, const std::vector<HostLinear>&
     return b;
 }
 
-PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin, int mode) {
-    const bool f32 = (mode == NRF_MMA_F32);
-    const int SUB = f32 ? 4 : 2;
-    PackedStream out;
+ParamLayout param_layout(const std::vector<HostLinear>& lin) {
+    ParamLayout lay;
+    int64_t off = 0;
+    for (const auto& l : lin) {
+        lay.w_off.push_back(off); off += (int64_t)l.out_f * l.in_f;
+        lay.b_off.push_back(off); off += l.out_f;
+        lay.in_f.push_back(l.in_f);
+    }
+    lay.total = off;
+    return lay;
+}
+
+namespace {
+// flat offset of element (output row r, K index k) of a packed layer, -1 = zero
+int64_t element_source(const LayerPlan& L, const ParamLayout& lay, int r, int k) {
+    if (L.transposed) {
+        const auto& ks = L.krow[k];
+        if (ks.first < 0 || L.rcol[r] < 0) return -1;
+        return lay.w_off[ks.first] + (int64_t)ks.second * lay.in_f[ks.first] + L.rcol[r];
+    }
+    const auto& rs = L.row[r];
+    if (rs.first < 0 || L.col[k] < 0) return -1;
+    return lay.w_off[rs.first] + (int64_t)rs.second * lay.in_f[rs.first] + L.col[k];
+}
+}  // namespace
+
+std::vector<int32_t> stream_sources(const NetPlan& plan, const ParamLayout& lay, bool f32) {
+    const int SUB = f32 ? 4 : 2, n_el = f32 ? 4 : 8;
     size_t total_frags = 0;
     for (const auto& L : plan.layers) {
         const size_t f = (size_t)L.MT * L.KT * SUB;
         total_frags += (f + kChunkFrags - 1) / kChunkFrags * kChunkFrags;
     }
-    out.bytes.assign(total_frags * kFragBytes, 0);
-    out.n_chunks = (uint32_t)(total_frags / kChunkFrags);
+    std::vector<int32_t> src(total_frags * 64 * n_el, -1);
     size_t frag = 0;
     for (const auto& L : plan.layers) {
         for (int m = 0; m < L.MT; ++m)
             for (int t = 0; t < L.KT; ++t)
-                for (int s = 0; s < SUB; ++s, ++frag) {
-                    uint8_t* dst = out.bytes.data() + frag * kFragBytes;
+                for (int s = 0; s < SUB; ++s, ++frag)
                     for (int lane = 0; lane < 64; ++lane) {
                         const int i = lane & 31, h = lane >> 5;
-                        const auto& rs = L.row[32 * m + i];
-                        const int n_el = f32 ? 4 : 8;
                         for (int e = 0; e < n_el; ++e) {
                             const int k = f32 ? (32 * t + 8 * s + 4 * h + e)
                                               : (32 * t + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3));
-                            float v = 0.0f;
-                            if (rs.first >= 0 && L.col[k] >= 0)
-                                v = lin[rs.first].w[(size_t)rs.second * lin[rs.first].in_f + L.col[k]];
-                            if (f32) {
-                                std::memcpy(dst + lane * 16 + e * 4, &v, 4);
-                            } else {
-                                const uint16_t q = (mode == NRF_MMA_BF16) ? f32_to_bf16(v) : f32_to_f16(v);
-                                std::memcpy(dst + lane * 16 + e * 2, &q, 2);
-                            }
+                            src[(frag * 64 + lane) * n_el + e] = (int32_t)element_source(L, lay, 32 * m + i, k);
                         }
                     }
-                }
         frag = (frag + kChunkFrags - 1) / kChunkFrags * kChunkFrags;   // every layer starts on a chunk boundary
     }
+    return src;
+}
+
+std::vector<int32_t> bias_sources(const NetPlan& plan, const ParamLayout& lay) {
+    std::vector<int32_t> b(plan.n_bias, -1);
+    for (const auto& L : plan.layers) {
+        if (L.transposed) continue;
+        for (int r = 0; r < 32 * L.MT; ++r)
+            if (L.row[r].first >= 0) b[L.bias_off + r] = (int32_t)(lay.b_off[L.row[r].first] + L.row[r].second);
+    }
+    return b;
+}
+
+PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin, int mode) {
+    const bool f32 = (mode == NRF_MMA_F32);
+    const ParamLayout lay = param_layout(lin);
+    std::vector<float> flat((size_t)lay.total);
+    for (size_t i = 0; i < lin.size(); ++i) {
+        std::memcpy(flat.data() + lay.w_off[i], lin[i].w.data(), lin[i].w.size() * sizeof(float));
+        std::memcpy(flat.data() + lay.b_off[i], lin[i].b.data(), lin[i].b.size() * sizeof(float));
+    }
+    const std::vector<int32_t> src = stream_sources(plan, lay, f32);
+    PackedStream out;
+    const size_t per_frag = f32 ? 256 : 512;
+    out.n_chunks = (uint32_t)(src.size() / per_frag / kChunkFrags);
+    out.bytes.assign(src.size() / per_frag * kFragBytes, 0);
+    for (size_t i = 0; i < src.size(); ++i) {
+        const float v = src[i] >= 0 ? flat[src[i]] : 0.0f;
+        if (f32) {
+            std::memcpy(out.bytes.data() + i * 4, &v, 4);
+        } else {
+            const uint16_t q = (mode == NRF_MMA_BF16) ? f32_to_bf16(v) : f32_to_f16(v);
+            std::memcpy(out.bytes.data() + i * 2, &q, 2);
+        }
+    }
     return out;
+}
+
+// ---------------------------------------------------------------------------
+// training path
+// ---------------------------------------------------------------------------
+// Saved-tensor slots (V1, n = n_layers):  0 = encoded input (KT0 tiles);  l = 1..n: output of layers.{l-1} after
+// ReLU (8 tiles);  n+l = dZ of layers.{l-1} (8 tiles);  2n+1 = dZ of the head [d rgb logits, d sigma] (1 tile).
+bool make_backward_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, NetPlan& plan, std::string& err) {
+    plan = NetPlan();
+    if (a.net != NRF_NET_V1) { err = "the training path is built for V1 (nerf_model.NeRFMLP) only"; return false; }
+    if (a.hidden != 256 || (int)lin.size() != expected_linears(a)) { err = "backward plan: unexpected architecture"; return false; }
+    const int n = a.n_layers, H = a.hidden, HT = H / 32;
+    auto rows_all = [&]() { std::vector<int> r(H); for (int i = 0; i < H; ++i) r[i] = i; return r; };
+    {   // head^T: K = [rgb_out rows 0..2, sigma_out row 0] -> dH_n
+        LayerPlan L; L.transposed = true; L.KT = 1; L.MT = HT; L.krow.assign(32, {-1, 0});
+        for (int c = 0; c < 3; ++c) L.krow[c] = {n + 1, c};
+        L.krow[3] = {n, 0};
+        L.rcol = rows_all();
+        plan.layers.push_back(std::move(L));
+    }
+    for (int l = n - 1; l >= 1; --l) {   // layers.l^T: dZ of layers.l -> dH of layers.{l-1}
+        LayerPlan L; L.transposed = true; L.KT = HT; L.MT = HT; L.krow.resize(H);
+        for (int k = 0; k < H; ++k) L.krow[k] = {l, k};
+        L.rcol = rows_all();
+        plan.layers.push_back(std::move(L));
+    }
+    int off = 0;
+    for (auto& L : plan.layers) { L.bias_off = off; off += 32 * L.MT; }
+    plan.n_bias = off;
+    return true;
+}
+
+bool make_train_plan(const nrf_arch& a, const NetPlan& fwd, const ParamLayout& lay, TrainPlan& tp, std::string& err) {
+    tp = TrainPlan();
+    if (a.net != NRF_NET_V1) { err = "the training path is built for V1 (nerf_model.NeRFMLP) only"; return false; }
+    const int n = a.n_layers;
+    if ((int)fwd.layers.size() != n + 1) { err = "train plan: forward plan has an unexpected layer count"; return false; }
+    tp.slot_tiles.assign(2 * n + 2, 8);
+    tp.slot_tiles[0] = fwd.layers[0].KT;
+    tp.slot_tiles[2 * n + 1] = 1;
+    for (int l = 0; l <= n; ++l) {
+        const LayerPlan& L = fwd.layers[l];
+        GradJobPlan J;
+        J.x_slot = l; J.dz_slot = l < n ? n + 1 + l : 2 * n + 1; J.KT = L.KT; J.MT = L.MT;
+        J.row_w.assign(32 * L.MT, -1); J.row_b.assign(32 * L.MT, -1);
+        std::vector<std::pair<int, int>> seen;
+        for (int r = 0; r < 32 * L.MT; ++r) {
+            const auto& rs = L.row[r];
+            if (rs.first < 0) continue;
+            bool dup = false;                   // the head tile repeats its rows for the second lane half: count once
+            for (const auto& q : seen) dup = dup || q == rs;
+            if (dup) continue;
+            seen.push_back(rs);
+            J.row_w[r] = (int32_t)(lay.w_off[rs.first] + (int64_t)rs.second * lay.in_f[rs.first]);
+            J.row_b[r] = (int32_t)(lay.b_off[rs.first] + rs.second);
+        }
+        J.col.assign(L.col.begin(), L.col.end());
+        tp.jobs.push_back(std::move(J));
+    }
+    return true;
 }
 
 }  // namespace nrf

@@ -21,7 +21,20 @@ struct LayerPlan {
     std::vector<int> col;                        // 32*KT: source column of the Linear(s), -1 = zero
     std::vector<std::pair<int, int>> row;        // 32*MT: (linear index, row of it), (-1,0) = zero row
     int bias_off = 0;                            // offset of this layer's 32*MT biases in the bias table
+    // backward-chain layer (dX = W^T dZ): element (r, k) = lin[krow[k].first].w[krow[k].second][rcol[r]]
+    bool transposed = false;
+    std::vector<std::pair<int, int>> krow;       // 32*KT: (linear index, row of it) feeding K index k, (-1,0) = zero
+    std::vector<int> rcol;                       // 32*MT: column of those Linears produced by output row r, -1 = zero
 };
+
+// The flat parameter vector of the training path: the Linears in list (state_dict) order, each as
+// weight (out_f*in_f, row-major) followed by bias (out_f).
+struct ParamLayout {
+    std::vector<int64_t> w_off, b_off;
+    std::vector<int> in_f;
+    int64_t total = 0;
+};
+ParamLayout param_layout(const std::vector<HostLinear>& lin);
 
 struct NetPlan {
     std::vector<LayerPlan> layers;               // in the order the kernel walks them
@@ -34,6 +47,28 @@ bool make_plan(const nrf_arch& arch, const std::vector<HostLinear>& lin, NetPlan
 
 // Number of Linear layers a state_dict of `arch` must hold (0 = unknown arch).
 int expected_linears(const nrf_arch& arch);
+
+// The backward chain of a network (train_impl.hpp walks the layers in this order); V1 and V2 are built.
+bool make_backward_plan(const nrf_arch& arch, const std::vector<HostLinear>& lin, NetPlan& plan, std::string& err);
+
+// Where every element of a packed stream comes from: flat-parameter offset, -1 = zero.  Elements in stream
+// order (fragment, lane, element); 512 per fragment in the 16-bit modes, 256 in the fp32 mode.  The host packer
+// and the device re-packer (after every optimizer step) are both a gather through this table.
+std::vector<int32_t> stream_sources(const NetPlan& plan, const ParamLayout& lay, bool f32);
+std::vector<int32_t> bias_sources(const NetPlan& plan, const ParamLayout& lay);
+
+// One weight-gradient job = one Linear (or the head pseudo-layer): dW[o][i] += sum_samples dZ[o] * X[i].
+// Saved-tensor slots: train_impl.hpp.
+struct GradJobPlan {
+    int x_slot = 0, dz_slot = 0, KT = 0, MT = 0;
+    std::vector<int32_t> row_w, row_b;           // 32*MT: flat offset of the weight row / of the bias, -1 = none
+    std::vector<int32_t> col;                    // 32*KT: column inside the weight row, -1 = none
+};
+struct TrainPlan {
+    std::vector<int> slot_tiles;                 // feature tiles (of 32) per saved-tensor slot
+    std::vector<GradJobPlan> jobs;
+};
+bool make_train_plan(const nrf_arch& arch, const NetPlan& fwd, const ParamLayout& lay, TrainPlan& tp, std::string& err);
 
 struct PackedStream {
     std::vector<uint8_t> bytes;                  // n_chunks * 16 KiB

@@ -144,6 +144,97 @@ __global__ void __launch_bounds__(kBlock) composite_kernel(const float* __restri
     }
 }
 
+// ---- backward of a9 (autograd through nerf_mlp.py:181-212) -------------------------
+// With v_i = g_rgb . c_i + g_depth * z_i + g_w[i] - [white_bkgd] * sum(g_rgb)  (so that dL = sum_i v_i dw_i):
+//   dL/dc_i     = w_i * g_rgb
+//   dL/dalpha_i = T_i * v_i - (sum_{j>i} w_j v_j) / (1 - alpha_i + 1e-10)
+//   dL/dsigma_i = dL/dalpha_i * dist_i * exp(-relu(sigma_i) dist_i) * [sigma_i > 0]
+// The suffix sum is a true reverse scan (segments walked back to front): "total - prefix" would lose every digit behind
+// an opaque sample, where the reference's +1e-10 makes the divisor 1e-10.  One WAVE per ray, LANE <-> sample.
+__device__ __forceinline__ float wave_incl_sum_rev(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float u = __shfl_down(v, d, 64);
+        if (lane + d < 64) v = __fadd_rn(v, u);
+    }
+    return v;
+}
+
+constexpr int kMaxSegments = 64;     // S <= 4096
+
+__global__ void __launch_bounds__(kBlock) composite_backward_kernel(const float* __restrict__ rgb, int rgb_stride, const float* __restrict__ sigma,
+                                                                    int sigma_stride, const float* __restrict__ z,
+                                                                    const float* __restrict__ rays_d, int64_t n_rays, int S, int white_bkgd,
+                                                                    const float* __restrict__ g_rgb, const float* __restrict__ g_depth,
+                                                                    const float* __restrict__ g_w, float* __restrict__ d_rgb,
+                                                                    int d_rgb_stride, float* __restrict__ d_sigma, int d_sigma_stride) {
+    __shared__ float seg_T[kBlock / 64][kMaxSegments];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t wave0 = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int n_seg = (S + 63) / 64;
+    for (int64_t r = wave0; r < n_rays; r += n_waves) {
+        const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+        const float norm = ray_norm(d);
+        const float gr = g_rgb ? g_rgb[r * 3] : 0.0f, gg = g_rgb ? g_rgb[r * 3 + 1] : 0.0f, gb = g_rgb ? g_rgb[r * 3 + 2] : 0.0f;
+        const float gd = g_depth ? g_depth[r] : 0.0f;
+        const float bg = white_bkgd ? __fadd_rn(__fadd_rn(gr, gg), gb) : 0.0f;
+        auto sample = [&](int s0, float& alpha, float& e, float& dist, float& f, float& zc, bool& valid, int64_t& i) {
+            const int s = s0 + lane;
+            valid = s < S;
+            i = r * S + (valid ? s : S - 1);
+            zc = z[i];
+            float zn = __shfl_down(zc, 1, 64);
+            if (lane == 63 && s + 1 < S) zn = z[i + 1];
+            const bool last = (s + 1 == S);
+            dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
+            e = valid ? expf(__fmul_rn(-fmaxf(sigma[i * sigma_stride], 0.0f), dist)) : 1.0f;
+            alpha = valid ? __fsub_rn(1.0f, e) : 0.0f;
+            f = valid ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+        };
+        // pass 1, front to back: transmittance entering every 64-sample segment
+        float T_in = 1.0f;
+        for (int k = 0; k < n_seg; ++k) {
+            float alpha, e, dist, f, zc; bool valid; int64_t i;
+            sample(64 * k, alpha, e, dist, f, zc, valid, i);
+            if (lane == 0) seg_T[wv][k] = T_in;
+            const float incl = wave_incl_prod(f, lane);
+            T_in = __fmul_rn(T_in, __shfl(incl, 63, 64));
+        }
+        // pass 2, back to front
+        float carry = 0.0f;                                  // sum of w_j v_j over all later segments
+        for (int k = n_seg - 1; k >= 0; --k) {
+            float alpha, e, dist, f, zc; bool valid; int64_t i;
+            sample(64 * k, alpha, e, dist, f, zc, valid, i);
+            const float incl = wave_incl_prod(f, lane);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T = __fmul_rn(seg_T[wv][k], excl);
+            const float w = __fmul_rn(alpha, T);
+            float v = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+            if (valid) {
+                cr = rgb[i * rgb_stride]; cg = rgb[i * rgb_stride + 1]; cb = rgb[i * rgb_stride + 2];
+                v = __fadd_rn(__fadd_rn(__fmul_rn(gr, cr), __fmul_rn(gg, cg)), __fmul_rn(gb, cb));
+                v = __fadd_rn(v, __fmul_rn(gd, zc));
+                if (g_w) v = __fadd_rn(v, g_w[i]);
+                v = __fsub_rn(v, bg);
+            }
+            const float wv_ = valid ? __fmul_rn(w, v) : 0.0f;
+            const float incl_rev = wave_incl_sum_rev(wv_, lane);
+            const float suffix = __fadd_rn(__fsub_rn(incl_rev, wv_), carry);     // strictly later samples
+            carry = __fadd_rn(carry, __shfl(incl_rev, 0, 64));
+            if (valid) {
+                const float d_alpha = __fsub_rn(__fmul_rn(T, v), suffix / f);
+                const float sg = sigma[i * sigma_stride];
+                d_sigma[i * d_sigma_stride] = sg > 0.0f ? __fmul_rn(__fmul_rn(d_alpha, dist), e) : 0.0f;
+                d_rgb[i * d_rgb_stride] = __fmul_rn(w, gr);
+                d_rgb[i * d_rgb_stride + 1] = __fmul_rn(w, gg);
+                d_rgb[i * d_rgb_stride + 2] = __fmul_rn(w, gb);
+            }
+        }
+    }
+}
+
 // ---- a3: ray_utils.py:86-143 (intent) --------------------------------------------------------
 // one thread per ray; its cdf (S+1) and new samples (Ni) live in a private LDS row
 __global__ void sample_pdf_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t n_rays, int S, int Ni,
@@ -278,6 +369,16 @@ int launch_composite(const float* rgb, int rgb_stride, const float* sigma, int s
     if (n_rays <= 0) return NRF_OK;
     hipLaunchKernelGGL(composite_kernel, dim3(grid_for(n_rays * 64, kBlock, 16384)), dim3(kBlock), 0, s, rgb, rgb_stride, sigma, sigma_stride, z,
                        rays_d, n_rays, S, white_bkgd, out_rgb, out_depth, out_w);
+    return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
+}
+
+int launch_composite_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
+                              int64_t n_rays, int S, int white_bkgd, const float* g_rgb, const float* g_depth, const float* g_w,
+                              float* d_rgb, int d_rgb_stride, float* d_sigma, int d_sigma_stride, hipStream_t s) {
+    if (n_rays <= 0) return NRF_OK;
+    if (S > 64 * kMaxSegments) return NRF_EINVAL;
+    hipLaunchKernelGGL(composite_backward_kernel, dim3(grid_for(n_rays * 64, kBlock, 16384)), dim3(kBlock), 0, s, rgb, rgb_stride, sigma,
+                       sigma_stride, z, rays_d, n_rays, S, white_bkgd, g_rgb, g_depth, g_w, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 

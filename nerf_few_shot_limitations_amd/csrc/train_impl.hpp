@@ -1,0 +1,334 @@
+// train_impl.hpp -- the training path of the V1 network (reference loop:
+// src/training/train.py:244-292, loss.backward() through nerf_model.py:16-24):
+//
+//   train_forward_kernel   forward chain of fused_impl.hpp's staged forward, one 32-sample tile per wave, which also
+//                          saves every layer's operand tiles (train_core.hpp);
+//   train_backward_kernel  dZ chain: head^T, then layers.{n-1..1}^T streamed like the forward weights, ReLU' taken
+//                          from the saved activations, every dZ tile saved;
+//   weight_grad_kernel     dW = dZ X^T, db = sum dZ over the samples: per Linear one 256 x 256 (or smaller) output
+//                          held in the accumulators of a workgroup, the sample axis split over workgroups, partial
+//                          sums added to the flat gradient vector with fp32 atomics;
+//   repack_kernel          flat fp32 parameters -> the packed operand streams (after every optimizer step);
+//   adam_kernel            torch.optim.Adam's update on the flat vectors (train.py:113-118).
+//
+// LANE <-> SAMPLE here (not ray): a training batch is a few thousand rays (baseline.yaml:32), so the sample
+// axis, not the ray axis, has to fill the chip; compositing and its backward are the staged kernels.
+#pragma once
+#include "fused_impl.hpp"
+#include "train_core.hpp"
+
+namespace nrf {
+
+struct TrainKArgs {
+    NetArgs net;              // forward: forward stream + bias table; backward: the transposed stream
+    const float* x_enc;       // (P, pe_dim)
+    int64_t n;                // samples
+    int64_t n_tiles;          // workgroup tiles of WAVES*32 samples
+    float* out4;              // forward: (P,4) written; backward: the same tensor, read (sigmoid')
+    const float* g_out4;      // backward: dL/d out4 (P,4)
+    char* ctx;                // saved tensors
+    int64_t slot_off[kMaxSlots];
+    int slot_tiles[kMaxSlots];
+};
+
+template <class Mode>
+__device__ __forceinline__ char* tile_ptr(const TrainKArgs& P, int slot, int64_t st, int t, int lane) {
+    return P.ctx + P.slot_off[slot] + ((st * P.slot_tiles[slot] + t) * (int64_t)tile_bytes<Mode>()) + lane * 16;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+template <class Mode, int WAVES, int LP>
+__global__ void __launch_bounds__(WAVES * 64) train_forward_kernel(const TrainKArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NRF_LDS char* lds = (NRF_LDS char*)smem;
+    NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
+    typedef typename Mode::Act Act;
+    typedef ActIO<Mode> IO;
+    constexpr int KT0 = pe_tiles(LP), HT = 8, PE = pe_dim(LP);
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    load_bias_table(bias, P.net.bias, P.net.n_bias);
+    Pipe<WAVES> pipe;
+    pipe.init(P.net.stream, P.net.n_chunks, lds, 0);
+    pipe.start();
+
+    for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        const int64_t st = tile * WAVES + wave;                  // this wave's 32-sample tile
+        const int64_t raw = st * 32 + c;
+        const int64_t sid = raw < P.n ? raw : P.n - 1;
+        Act A[HT][1], B[HT][1];
+        {
+            Act enc[KT0][1];
+            const float* xin = P.x_enc + sid * PE;
+            f32x16 e[KT0];
+            static_for<16 * KT0>([&](auto u_) {                  // positional_encoding.py order -> operand order (feature_map.hpp)
+                constexpr int u = decltype(u_)::value;
+                constexpr int i0 = pe_ref_index(LP, u, 0), i1 = pe_ref_index(LP, u, 1);
+                float val = 0.0f;
+                if constexpr (i0 >= 0 && i1 >= 0) val = xin[h ? i1 : i0];
+                else if constexpr (i0 >= 0) val = h ? 0.0f : xin[i0];
+                else if constexpr (i1 >= 0) val = h ? xin[i1] : 0.0f;
+                e[u / 16][u % 16] = val;
+            });
+#pragma unroll
+            for (int t = 0; t < KT0; ++t) {
+                enc[t][0] = Mode::template to_act<false>(e[t]);
+                IO::store(tile_ptr<Mode>(P, 0, st, t, lane), enc[t][0]);
+            }
+            dense<Mode, KT0, HT, 1>(pipe, bias, h, enc, [&](auto m_, f32x16(&acc)[1]) {
+                constexpr int m = decltype(m_)::value;
+                A[m][0] = Mode::template to_act<true>(acc[0]);
+                IO::store(tile_ptr<Mode>(P, 1, st, m, lane), A[m][0]);
+            });
+        }
+        auto layer = [&](const Act (&in)[HT][1], Act (&out)[HT][1], int slot, int boff) {
+            dense<Mode, HT, HT, 1>(pipe, bias + boff, h, in, [&](auto m_, f32x16(&acc)[1]) {
+                constexpr int m = decltype(m_)::value;
+                out[m][0] = Mode::template to_act<true>(acc[0]);
+                IO::store(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
+            });
+        };
+        int boff = 32 * HT, slot = 2;
+        const int hidden = P.net.n_layers - 1;
+        for (int p = 0; p < hidden / 2; ++p) {
+            layer(A, B, slot++, boff); boff += 32 * HT;
+            layer(B, A, slot++, boff); boff += 32 * HT;
+        }
+        f32x16 head[1];
+        if (hidden & 1) {
+            layer(A, B, slot++, boff); boff += 32 * HT;
+            dense_head<Mode, HT, 1>(pipe, bias + boff, h, B, head);
+        } else {
+            dense_head<Mode, HT, 1>(pipe, bias + boff, h, A, head);
+        }
+        if (h == 0 && raw < P.n) {
+            const float r = sigmoid_sel<Mode::FAST_EXP>(head[0][0]), g = sigmoid_sel<Mode::FAST_EXP>(head[0][1]),
+                        b = sigmoid_sel<Mode::FAST_EXP>(head[0][2]);
+            *(float4*)(P.out4 + raw * 4) = make_float4(r, g, b, head[0][3]);      // nerf_model.py:22-24
+        }
+    }
+    pipe.drain();
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward chain
+// ---------------------------------------------------------------------------------------------
+// ReLU masks: the saved activation tile of the layer below is needed in the epilogue of every output tile; the loads
+// run kMaskAhead tiles ahead of their use (HBM latency is several tile times)
+template <class Mode, int WAVES, int LP>
+__global__ void __launch_bounds__(WAVES * 64) train_backward_kernel(const TrainKArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    NRF_LDS char* lds = (NRF_LDS char*)smem;
+    NRF_LDS float* zero_bias = (NRF_LDS float*)(lds + kLdsRing);
+    typedef typename Mode::Act Act;
+    typedef ActIO<Mode> IO;
+    constexpr int HT = 8;
+    constexpr int kMaskAhead = 4;
+
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x; i < 32 * HT; i += blockDim.x) zero_bias[i] = 0.0f;     // the chain has no bias: accumulators start at 0
+    __syncthreads();
+    Pipe<WAVES> pipe;
+    pipe.init(P.net.stream, P.net.n_chunks, lds, 0);
+    pipe.start();
+    const int n = P.net.n_layers;
+
+    for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
+        const int64_t st = tile * WAVES + wave;
+        const int64_t raw = st * 32 + c;
+        // masks of layer L (slot L, L = n .. 1), tiles 0..7, as one linear sequence q = (n - L) * 8 + m
+        Act mk[kMaskAhead];
+        const int n_mask = 8 * n;
+        auto mask_ptr = [&](int q) { return tile_ptr<Mode>(P, n - (q >> 3), st, q & 7, lane); };
+#pragma unroll
+        for (int q = 0; q < kMaskAhead; ++q) mk[q] = IO::template load<Act>(mask_ptr(q));
+
+        Act G[1][1];
+        {   // d out4 -> d [rgb logits, sigma]: rows 0..3 of one operand tile (registers 0..3 of lane half 0)
+            f32x16 e = {};
+            if (h == 0 && raw < P.n) {
+                const float4 o = *(const float4*)(P.out4 + raw * 4);
+                const float4 g = *(const float4*)(P.g_out4 + raw * 4);
+                e[0] = g.x * o.x * (1.0f - o.x);                                    // sigmoid'
+                e[1] = g.y * o.y * (1.0f - o.y);
+                e[2] = g.z * o.z * (1.0f - o.z);
+                e[3] = g.w;                                                         // sigma_out has no activation
+            }
+            G[0][0] = Mode::template to_act<false>(e);
+            IO::store(tile_ptr<Mode>(P, 2 * n + 1, st, 0, lane), G[0][0]);
+        }
+        Act A[HT][1], B[HT][1];
+        int q0 = 0;       // mask sequence index of tile 0 of the layer being produced
+        auto epilogue = [&](auto m_, f32x16(&acc)[1], Act (&out)[HT][1], int slot_dz) {
+            constexpr int m = decltype(m_)::value;
+            out[m][0] = Masked<Mode>::apply(acc[0], mk[m % kMaskAhead]);
+            const int qn = q0 + m + kMaskAhead;
+            if (qn < n_mask) mk[m % kMaskAhead] = IO::template load<Act>(mask_ptr(qn));
+            IO::store(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
+        };
+        static_assert(HT % kMaskAhead == 0, "mask ring indexed by the tile number inside a layer");
+        // head^T -> dZ of layers.{n-1}
+        dense<Mode, 1, HT, 1>(pipe, zero_bias, h, G, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, A, 2 * n); });
+        q0 += 8;
+        // layers.l^T, l = n-1 .. 1: dZ_l -> dZ_{l-1}
+        const int hidden = n - 1;
+        int slot = 2 * n - 1;
+        for (int p = 0; p < hidden / 2; ++p) {
+            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, B, slot); });
+            --slot; q0 += 8;
+            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, B, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, A, slot); });
+            --slot; q0 += 8;
+        }
+        if (hidden & 1) {
+            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, B, slot); });
+        }
+    }
+    pipe.drain();
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight gradients
+// ---------------------------------------------------------------------------------------------
+struct GradJob {
+    int64_t x_off, dz_off;      // slot bases inside the context
+    int KT, MT;                 // feature tiles of X / of dZ
+    int map_off;                // this job's row_w | row_b | col tables inside `maps` (ints)
+    int pad;
+};
+
+struct GradKArgs {
+    const char* ctx;
+    float* grad;                // flat gradient vector, accumulated into
+    const int32_t* maps;
+    GradJob jobs[kMaxJobs];
+    int n_jobs;
+    int splits;                 // workgroups per job along the sample axis
+    int64_t n_tiles32;          // 32-sample tiles
+};
+
+// RT x CT output tiles (of 32 x 32) per wave; 8 waves = (8/RT) row groups x (RT*CT/8 ...) column groups
+template <class Mode, int RT, int CT>
+__global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
+    typedef typename Mode::Act Act;
+    typedef ActIO<Mode> IO;
+    constexpr int RG = 8 / RT;                       // row groups among the 8 waves
+    constexpr int TB = tile_bytes<Mode>();
+    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cgroups = 8 / RG;                      // column groups among the waves
+    const int jobs_x = (8 + cgroups * CT - 1) / (cgroups * CT);    // workgroups needed to span 8 column tiles
+    const int job = blockIdx.x / (P.splits * jobs_x);
+    const int rem = blockIdx.x % (P.splits * jobs_x);
+    const int split = rem / jobs_x, xhalf = rem % jobs_x;
+    const GradJob J = P.jobs[job];
+    const int row0 = (wave % RG) * RT, col0 = ((wave / RG) + xhalf * cgroups) * CT;
+    if (row0 >= J.MT || col0 >= J.KT) return;        // wave-uniform; the kernel has no barriers
+
+    Transposer<Mode> tr;
+    tr.init(lane);
+    f32x16 acc[RT][CT];
+    float bsum[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        bsum[i] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x16{};
+    }
+    const int64_t per = (P.n_tiles32 + P.splits - 1) / P.splits;
+    const int64_t t0 = split * per, t1 = (t0 + per < P.n_tiles32) ? t0 + per : P.n_tiles32;
+    const char* xb = P.ctx + J.x_off + lane * 16;
+    const char* zb = P.ctx + J.dz_off + lane * 16;
+    for (int64_t st = t0; st < t1; ++st) {
+        Act tz[RT], tx[CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) {
+            if (row0 + i < J.MT) {
+                const f32x16 t = tr.run(IO::template load<Act>(zb + (st * J.MT + row0 + i) * (int64_t)TB));
+                float s = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += t[r];
+                bsum[i] += s;
+                tz[i] = Mode::template to_act<false>(t);
+            } else {
+                tz[i] = Mode::template to_act<false>(f32x16{});
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if (col0 + j < J.KT) tx[j] = Mode::template to_act<false>(tr.run(IO::template load<Act>(xb + (st * J.KT + col0 + j) * (int64_t)TB)));
+            else tx[j] = Mode::template to_act<false>(f32x16{});
+        }
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) OuterMma<Mode>::run(acc[i][j], tz[i], tx[j]);
+    }
+    // flush: accumulator tile rows = dZ features (registers), columns = X features (lanes)
+    const int32_t* row_w = P.maps + J.map_off;
+    const int32_t* row_b = row_w + 320;
+    const int32_t* colm = row_b + 320;
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        if (row0 + i >= J.MT) continue;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if (col0 + j >= J.KT) continue;
+            const int col = colm[32 * (col0 + j) + c];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = 32 * (row0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int w = row_w[o];
+                if (w >= 0 && col >= 0) unsafeAtomicAdd(P.grad + w + col, acc[i][j][r]);
+            }
+        }
+        if (col0 == 0) {                              // one column group owns the bias sums
+            const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+            const int b = row_b[32 * (row0 + i) + c];
+            if (h == 0 && b >= 0) unsafeAtomicAdd(P.grad + b, s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// parameter re-pack and Adam
+// ---------------------------------------------------------------------------------------------
+// out element i = convert(flat[src[i]]) (0 where src < 0); mode selects the operand type
+__global__ void __launch_bounds__(256) repack16_kernel(const float* __restrict__ flat, const int32_t* __restrict__ src, int64_t n_pairs,
+                                                      int bf16, uint32_t* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
+        const int2 s = *(const int2*)(src + 2 * i);
+        const float a = s.x >= 0 ? flat[s.x] : 0.0f, b = s.y >= 0 ? flat[s.y] : 0.0f;
+        out[i] = bf16 ? (uint32_t)pack_pair<bf16x2, false>(a, b) : (uint32_t)pack_pair<f16x2, false>(a, b);
+    }
+}
+
+__global__ void __launch_bounds__(256) repack32_kernel(const float* __restrict__ flat, const int32_t* __restrict__ src, int64_t n,
+                                                      float* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int s = src[i];
+        out[i] = s >= 0 ? flat[s] : 0.0f;
+    }
+}
+
+// torch.optim.Adam (train.py:113-118; no amsgrad, weight decay added to the gradient, bias-corrected moments):
+//   g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
+                                                  float wd, float bc1, float bc2_sqrt) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.0f) gi = __fadd_rn(gi, __fmul_rn(wd, pi));
+        const float mi = __fadd_rn(__fmul_rn(b1, m[i]), __fmul_rn(1.0f - b1, gi));
+        const float vi = __fadd_rn(__fmul_rn(b2, v[i]), __fmul_rn(__fmul_rn(1.0f - b2, gi), gi));
+        m[i] = mi; v[i] = vi;
+        const float denom = __fadd_rn(sqrtf(vi) / bc2_sqrt, eps);
+        p[i] = __fsub_rn(pi, __fmul_rn(lr / bc1, mi / denom));
+    }
+}
+
+}  // namespace nrf

@@ -8,9 +8,9 @@ Two constructor forms, as the reference uses them:
             (positions (P,3), directions (P,3), dino (P,C)|None) -> (rgb (P,3), density (P,1))
             src/training/train.py:82-89,229; the module tree mirrors
             src/models/nerf_mlp.py:86-158 (NeRFWithDINO) so checkpoints load by name.
-Forward is inference only: the backward of the fused path is not built yet
- and a grad-enabled call raises instead of silently
-detaching.
+With grad enabled the legacy (V1) form runs the training kernels (training.py: saved
+activations, transposed-stream backward, MFMA weight gradients); the trainer forms (V2/V3)
+are inference only and a grad-enabled call raises instead of silently detaching.
 """
 from __future__ import annotations
 
@@ -98,7 +98,11 @@ class NeRFMLP(nn.Module):
             self.color_mlp = _ColorMLP(hidden_dim, de, hidden_dim // 2)
         self._handle = None
         self._handle_dev = None
-        self._packed = None
+        self._packed = None          # parameter versions the packed streams were built from
+        self._packed_modes = None    # modes whose streams match _packed (None = all three)
+        self._gen = 0                # bumped by optimizers that update the flat vector behind autograd's back
+        self._flat = None
+        self._train_ready = False
 
     # ---- parameters in the order include/nerfhip.h documents ------------------------------------
     def linears(self):
@@ -136,7 +140,23 @@ class NeRFMLP(nn.Module):
         return arr, len(lins), keep
 
     def _versions(self):
-        return tuple((p.data_ptr(), p._version) for m in self.linears() for p in (m.weight, m.bias))
+        return tuple((p.data_ptr(), p._version) for m in self.linears() for p in (m.weight, m.bias)) + (self._gen,)
+
+    def flat_params(self):
+        """training.FlatParams of this module (parameters as views into one flat device vector)."""
+        if self._flat is None:
+            from .training import FlatParams
+            self._flat = FlatParams(self)
+        return self._flat
+
+    def _flat_on(self, idx):
+        """The flat parameter vector if the parameters currently are views into it on device `idx`, else None."""
+        fp = self._flat
+        if fp is None or fp.flat is None or not fp.flat.is_cuda or fp.flat.device.index != idx:
+            return None
+        base = fp.flat.data_ptr()
+        ok = all(p.data_ptr() == base + 4 * off for p, off in zip(fp.params(), fp.offsets))
+        return fp.flat if ok else None
 
     def handle(self, device=None):
         """The nrf_model* for this module on `device`, (re)packed if the parameters changed."""
@@ -147,10 +167,20 @@ class NeRFMLP(nn.Module):
         device = torch.device(device)
         idx = device.index if device.index is not None else torch.cuda.current_device()
         ver = self._versions()
-        if self._handle is not None and self._handle_dev == idx and self._packed == ver:
+        mode = L.MMA_MODES[self.mma_mode]
+        same = self._handle is not None and self._handle_dev == idx
+        if same and self._packed == ver and (self._packed_modes is None or mode in self._packed_modes):
+            return self._handle
+        flat = self._flat_on(idx) if same else None
+        if flat is not None:
+            # parameters live in the flat device vector (training): re-pack this mode's streams on the device
+            with torch.cuda.device(idx):
+                L.check(L.lib().nrf_model_update_device(self._handle, L.ptr(flat), 1 << mode, L.stream_ptr()))
+            self._packed_modes = ({mode} if self._packed != ver or self._packed_modes is None else self._packed_modes | {mode})
+            self._packed = ver
             return self._handle
         arr, n, keep = self._host_linears()
-        if self._handle is not None and self._handle_dev == idx:
+        if same:
             with torch.cuda.device(idx):
                 L.check(L.lib().nrf_model_update(self._handle, arr, n, L.stream_ptr()))
         else:
@@ -159,8 +189,9 @@ class NeRFMLP(nn.Module):
             arch = self._arch()
             L.check(L.lib().nrf_model_create(C.byref(h), idx, C.byref(arch), arr, n))
             self._handle, self._handle_dev = h, idx
+            self._train_ready = False
         del keep
-        self._packed = ver
+        self._packed, self._packed_modes = ver, None
         return self._handle
 
     def release(self):
@@ -174,13 +205,16 @@ class NeRFMLP(nn.Module):
         except Exception:
             pass
 
-    def _no_grad_only(self):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("NeRFMLP.forward is inference-only: the backward of the fused HIP path is not built "
-                                      "(SURVEY.md section 8 f1). Call it under torch.no_grad().")
+    def _wants_grad(self):
+        return torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
 
     def forward(self, positions, directions=None, dino_features=None):
-        self._no_grad_only()
+        if self._wants_grad():
+            if self.net != L.NRF_NET_V1:
+                raise NotImplementedError("the backward of the HIP path is built for the legacy NeRFMLP(pos_dim=63) form only "
+                                          "(SURVEY.md section 8 f1); call the trainer forms under torch.no_grad().")
+            from .training import mlp_v1_train
+            return mlp_v1_train(self, positions)
         mode = L.MMA_MODES[self.mma_mode]
         x = L.dev_f32(positions)
         h = self.handle(x.device)

@@ -1,0 +1,219 @@
+"""The training path: what `loss.backward()` / `optimizer.step()` of the reference's loops
+(src/training/train_minimal.py:80-127, src/training/train.py:244-292) run through on the GPU.
+
+  * `mlp_v1_train`   nerf_model.NeRFMLP.forward with grad enabled: libnerfhip's forward that saves
+                     every layer's operand tiles, and a backward made of the transposed weight-stream
+                     chain + MFMA weight-gradient kernel (csrc/train_impl.hpp);
+  * `composite`      nerf_mlp.VolumeRenderer / volume_render_radiance with grad enabled;
+  * `FlatParams`     the module's parameters as views into one flat fp32 vector, so that an
+                     optimizer step is visible to the kernels without leaving the device;
+  * `Adam`           torch.optim.Adam's update as one kernel on the flat vectors (train.py:113-118).
+
+There is no PyTorch fallback: without libnerfhip.so / a gfx950 GPU every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+# ---------------------------------------------------------------------------------------------
+# flat parameter storage
+# ---------------------------------------------------------------------------------------------
+class FlatParams:
+    """Parameters of `module.linears()` (weight, bias per Linear, state_dict order == include/nerfhip.h's flat
+    layout) re-homed as views into one contiguous fp32 device vector.  The nn.Parameter objects stay the same
+    (optimizers keep working); only their storage moves."""
+
+    def __init__(self, module):
+        self.module = module
+        self.flat = None
+        self.offsets = []
+
+    def params(self):
+        return [p for m in self.module.linears() for p in (m.weight, m.bias)]
+
+    def ensure(self):
+        ps = self.params()
+        dev = ps[0].device
+        if not ps[0].is_cuda:
+            raise RuntimeError("training runs on the GPU: move the module with .to('cuda') first")
+        if self.flat is not None and self.flat.device == dev:
+            base = self.flat.data_ptr()
+            if all(p.data_ptr() == base + 4 * off and p.dtype == torch.float32 for p, off in zip(ps, self.offsets)):
+                return self.flat
+        total = sum(p.numel() for p in ps)
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        offsets, off = [], 0
+        with torch.no_grad():
+            for p in ps:
+                n = p.numel()
+                flat[off:off + n].copy_(p.detach().reshape(-1).to(torch.float32))
+                p.data = flat[off:off + n].view(p.shape)
+                offsets.append(off)
+                off += n
+        self.flat, self.offsets = flat, offsets
+        return flat
+
+    def views(self, vec):
+        """Per-parameter views of another flat vector of the same layout (gradients, Adam moments)."""
+        return [vec[off:off + p.numel()].view(p.shape) for p, off in zip(self.params(), self.offsets)]
+
+
+def _train_handle(module, dev):
+    """nrf_model* with forward AND backward streams matching the current parameter values."""
+    module.flat_params().ensure()
+    h = module.handle(dev)
+    mode = L.MMA_MODES[module.mma_mode]
+    if not module._train_ready:
+        # first use: build the backward plan, then pack both directions from the flat vector
+        with torch.cuda.device(dev):
+            if L.lib().nrf_train_context_bytes(h, mode, 1) < 0:
+                raise L.NrfError(-2, L.lib().nrf_last_error().decode("utf-8", "replace"))
+            L.check(L.lib().nrf_model_update_device(h, L.ptr(module.flat_params().flat), 1 << mode, L.stream_ptr()))
+        module._train_ready = True
+        module._packed, module._packed_modes = module._versions(), {mode}
+    return h, mode
+
+
+class _MLPV1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x_enc, *params):
+        dev = x_enc.device
+        h, mode = _train_handle(module, dev)
+        n = x_enc.shape[0]
+        out = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = L.lib().nrf_train_context_bytes(h, mode, n)
+            if nbytes < 0:
+                raise L.NrfError(-2, L.lib().nrf_last_error().decode("utf-8", "replace"))
+            buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+            L.check(L.lib().nrf_mlp_forward_train_v1(h, mode, L.ptr(x_enc), n, L.ptr(out), C.c_void_p(buf.data_ptr()), nbytes, L.stream_ptr()))
+        ctx.module, ctx.buf, ctx.nbytes, ctx.n, ctx.mode = module, buf, nbytes, n, mode
+        ctx.versions = module._versions()
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        module = ctx.module
+        if module._versions() != ctx.versions:
+            raise RuntimeError("NeRFMLP parameters were modified between forward and backward: the saved activations "
+                               "no longer match the packed weights")
+        (out,) = ctx.saved_tensors
+        dev = out.device
+        g = g_out.to(torch.float32).contiguous()
+        fp = module.flat_params()
+        grad = torch.zeros_like(fp.flat)
+        with torch.cuda.device(dev):
+            L.check(L.lib().nrf_mlp_backward_v1(module._handle, ctx.mode, L.ptr(out), L.ptr(g), ctx.n, C.c_void_p(ctx.buf.data_ptr()), ctx.nbytes,
+                                                L.ptr(grad), L.stream_ptr()))
+        ctx.buf = None
+        return (None, None, *fp.views(grad))
+
+
+def mlp_v1_train(module, x_enc):
+    """(P, 63) encoded points -> (P, 4) = [sigmoid rgb, raw sigma], differentiable with respect to the parameters."""
+    x = L.dev_f32(x_enc)
+    pe = 3 * (2 * module.pos_freq + 1)
+    flat_in = x.reshape(-1, pe)
+    module.flat_params().ensure()
+    out = _MLPV1Fn.apply(module, flat_in, *module.flat_params().params())
+    return out.reshape(*x.shape[:-1], 4)
+
+
+# ---------------------------------------------------------------------------------------------
+# compositing
+# ---------------------------------------------------------------------------------------------
+class _CompositeFn(torch.autograd.Function):
+    """rgb (R,S,Cs>=3 strided), sigma (R,S strided) -> rgb_map, depth, weights; gradients for rgb and sigma only
+    (the reference never differentiates the sample depths or ray directions)."""
+
+    @staticmethod
+    def forward(ctx, packed, z, d, white_bkgd):
+        R, S = z.shape
+        dev = z.device
+        out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+        out_depth = torch.empty((R,), dtype=torch.float32, device=dev)
+        out_w = torch.empty((R, S), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.lib().nrf_composite(L.ptr(packed), 4, C.c_void_p(packed.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S,
+                                          int(bool(white_bkgd)), L.ptr(out_rgb), L.ptr(out_depth), L.ptr(out_w), L.stream_ptr()))
+        ctx.save_for_backward(packed, z, d)
+        ctx.white = int(bool(white_bkgd))
+        ctx.set_materialize_grads(False)      # unused outputs arrive as None, not as zero tensors
+        return out_rgb, out_depth, out_w
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_w):
+        packed, z, d = ctx.saved_tensors
+        R, S = z.shape
+        dev = z.device
+
+        def prep(g):
+            return None if g is None else g.to(torch.float32).contiguous()
+        g_rgb, g_depth, g_w = prep(g_rgb), prep(g_depth), prep(g_w)
+        d_packed = torch.empty_like(packed)
+        with torch.cuda.device(dev):
+            L.check(L.lib().nrf_composite_backward(L.ptr(packed), 4, C.c_void_p(packed.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, ctx.white,
+                                                   L.ptr(g_rgb), L.ptr(g_depth), L.ptr(g_w), L.ptr(d_packed), 4,
+                                                   C.c_void_p(d_packed.data_ptr() + 12), 4, L.stream_ptr()))
+        return d_packed, None, None, None
+
+
+def composite(rgb_sigma, z, d, white_bkgd=False):
+    """Differentiable alpha compositing of (R,S,4) [r,g,b,sigma] rows."""
+    return _CompositeFn.apply(rgb_sigma.contiguous(), z, d, white_bkgd)
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------
+class Adam:
+    """torch.optim.Adam(params, lr, betas, eps, weight_decay) for a NeRFMLP whose parameters live in a FlatParams
+    vector: one kernel per step.  Same update rule and defaults as the reference's optimizer (train.py:113-118)."""
+
+    def __init__(self, module, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.module = module
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.step_count = 0
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self.grad = None
+
+    def _buffers(self):
+        fp = self.module.flat_params()
+        flat = fp.ensure()
+        if self.exp_avg is None or self.exp_avg.shape != flat.shape or self.exp_avg.device != flat.device:
+            self.exp_avg = torch.zeros_like(flat)
+            self.exp_avg_sq = torch.zeros_like(flat)
+        return fp, flat
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.module.flat_params().params():
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    def step(self):
+        fp, flat = self._buffers()
+        ps = fp.params()
+        # gather the gradients autograd left on the parameters into the flat layout (a no-op copy when they already are views of one vector)
+        g = self.grad if self.grad is not None and self.grad.shape == flat.shape and self.grad.device == flat.device else torch.empty_like(flat)
+        self.grad = g
+        gv = fp.views(g)
+        with torch.no_grad():
+            for p, v in zip(ps, gv):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+        self.step_count += 1
+        with torch.no_grad(), torch.cuda.device(flat.device):
+            L.check(L.lib().nrf_adam_step(L.ptr(flat), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), flat.numel(), self.lr,
+                                          self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, L.stream_ptr()))
+        self.module._gen += 1            # the packed streams are now older than the parameters

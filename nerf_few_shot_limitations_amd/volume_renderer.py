@@ -31,6 +31,11 @@ class VolumeRenderer(nn.Module):
             density = density + torch.randn_like(density) * noise_std
         z = L.dev_f32(z_vals)
         R, S = z.shape
+        if torch.is_grad_enabled() and (getattr(rgb, "requires_grad", False) or getattr(density, "requires_grad", False)):
+            # training (train.py:236 inside loss.backward()'s graph): differentiable with respect to rgb and density
+            from .training import composite
+            packed = torch.cat([rgb.reshape(R, S, 3), density.reshape(R, S, 1)], dim=-1).to(device=z.device, dtype=torch.float32)
+            return composite(packed, z, L.dev_f32(rays_d, z.device).reshape(R, 3), white_bkgd)
         c = L.dev_f32(rgb, z.device).reshape(R, S, 3)
         sg = L.dev_f32(density, z.device).reshape(R, S)
         d = L.dev_f32(rays_d, z.device).reshape(R, 3)
@@ -40,6 +45,19 @@ class VolumeRenderer(nn.Module):
 def volume_render_radiance(rgb_sigma, z_vals, rays_d, noise_std=0.0):
     """rgb_sigma (H,W,S,4)=[r,g,b,sigma], z_vals (H,W,S), rays_d (H,W,3) -> rgb (H,W,3)."""
     L.require_gpu()
+    if torch.is_grad_enabled() and getattr(rgb_sigma, "requires_grad", False):
+        # train_minimal.py:53,120 -- the loss is taken on this output
+        from .training import composite
+        if noise_std > 0.0:
+            noise = torch.zeros_like(rgb_sigma)
+            noise[..., 3] = noise_std * torch.randn_like(rgb_sigma[..., 3])
+            rgb_sigma = rgb_sigma + noise
+        lead = tuple(rgb_sigma.shape[:-2])
+        S = rgb_sigma.shape[-2]
+        packed = rgb_sigma.reshape(-1, S, 4).to(torch.float32)
+        z = L.dev_f32(z_vals, packed.device).reshape(-1, S)
+        d = L.dev_f32(rays_d, packed.device).reshape(-1, 3)
+        return composite(packed, z, d, False)[0].reshape(*lead, 3)
     rs = L.dev_f32(rgb_sigma)
     if noise_std > 0.0:
         rs = rs.clone()

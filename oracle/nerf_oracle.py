@@ -488,3 +488,50 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     """-10 log10(mse), data range 1 (src/training/train_multiscale.py:294-295)."""
     mse = torch.mean((a.double() - b.double()) ** 2).item()
     return float("inf") if mse == 0 else -10.0 * math.log10(mse)
+
+
+# --------------------------------------------------------------------------
+# f1  training path: gradients of the V1 MLP as the HIP kernels round them
+# --------------------------------------------------------------------------
+
+def quantize(x: torch.Tensor, mode: str) -> torch.Tensor:
+    """Round to the MFMA operand type of `mode` ('bf16' | 'f16' | 'f32') and come back to fp32."""
+    if mode == "bf16":
+        return x.to(torch.bfloat16).to(torch.float32)
+    if mode == "f16":
+        return x.to(torch.float16).to(torch.float32)
+    return x.to(torch.float32)
+
+
+def mlp_v1_train_emulated(p: Dict[str, torch.Tensor], x_enc: torch.Tensor, g_out: torch.Tensor, mode: str = "f32"):
+    """Forward + backward of src/models/nerf_model.py:16-24 with every MFMA operand (weights, activations,
+    masked gradients) rounded to `mode`'s operand type and fp32 accumulation -- the arithmetic of
+    csrc/train_impl.hpp.  With mode='f32' this IS autograd's result up to summation order.
+
+    Returns (out4, grads {name: tensor}, acts [h_0..h_n], dzs [dz_1..dz_n, dz_head])."""
+    q = lambda t: quantize(t, mode)
+    n = 0
+    while f"layers.{n}.weight" in p:
+        n += 1
+    h = [q(x_enc.to(torch.float32))]
+    for i in range(n):
+        h.append(q(F.relu(h[-1] @ q(p[f"layers.{i}.weight"]).T + p[f"layers.{i}.bias"])))
+    sigma = h[-1] @ q(p["sigma_out.weight"]).T + p["sigma_out.bias"]
+    rgb = torch.sigmoid(h[-1] @ q(p["rgb_out.weight"]).T + p["rgb_out.bias"])
+    out = torch.cat([rgb, sigma], -1)
+    g_out = g_out.to(torch.float32)
+    d_head = q(torch.cat([g_out[:, :3] * rgb * (1.0 - rgb), g_out[:, 3:4]], -1))        # [d rgb logits, d sigma]
+    grads = {
+        "rgb_out.weight": d_head[:, :3].T @ h[-1], "rgb_out.bias": d_head[:, :3].sum(0),
+        "sigma_out.weight": d_head[:, 3:4].T @ h[-1], "sigma_out.bias": d_head[:, 3:4].sum(0),
+    }
+    dh = d_head[:, :3] @ q(p["rgb_out.weight"]) + d_head[:, 3:4] @ q(p["sigma_out.weight"])
+    dzs = []
+    for i in range(n - 1, -1, -1):
+        dz = q(dh * (h[i + 1] > 0).to(torch.float32))
+        dzs.append(dz)
+        grads[f"layers.{i}.weight"] = dz.T @ h[i]
+        grads[f"layers.{i}.bias"] = dz.sum(0)
+        if i > 0:
+            dh = dz @ q(p[f"layers.{i}.weight"])
+    return out, grads, h, dzs[::-1] + [d_head]

@@ -210,62 +210,84 @@ struct GradKArgs {
     int64_t n_tiles32;          // 32-sample tiles
 };
 
-// RT x CT output tiles (of 32 x 32) per wave; 8 waves = (8/RT) row groups x (RT*CT/8 ...) column groups
-template <class Mode, int RT, int CT>
+// One workgroup (8 waves) = one Linear x one slab of samples; its 256 x 256 fp32 output lives in the accumulators
+// (wave w: rows 64*(w&3).., columns 128*(w>>2)..).  HBM-bound: 1 KiB of saved operands per sample and layer against
+// 131 kFLOP.  Per stage of ST sample tiles, wave w transposes dZ tile w and X tile w of every sample tile on the
+// matrix core (train_core.hpp) -- each tile exactly once per workgroup -- and parks the transposed operand tiles in
+// LDS, where all waves read the 2 + 4 tiles their outputs need; the saved tiles of the next stage are already in
+// flight (registers) while the current one is multiplied.  Two LDS buffers, one barrier per stage.
+template <class Mode, int ST>
 __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mode::Act Act;
     typedef ActIO<Mode> IO;
-    constexpr int RG = 8 / RT;                       // row groups among the 8 waves
+    constexpr int RT = 2, CT = 4;
     constexpr int TB = tile_bytes<Mode>();
+    constexpr int kStageBytes = ST * 16 * TB;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int cgroups = 8 / RG;                      // column groups among the waves
-    const int jobs_x = (8 + cgroups * CT - 1) / (cgroups * CT);    // workgroups needed to span 8 column tiles
-    const int job = blockIdx.x / (P.splits * jobs_x);
-    const int rem = blockIdx.x % (P.splits * jobs_x);
-    const int split = rem / jobs_x, xhalf = rem % jobs_x;
+    const int job = blockIdx.x / P.splits, split = blockIdx.x % P.splits;
     const GradJob J = P.jobs[job];
-    const int row0 = (wave % RG) * RT, col0 = ((wave / RG) + xhalf * cgroups) * CT;
-    if (row0 >= J.MT || col0 >= J.KT) return;        // wave-uniform; the kernel has no barriers
+    const int row0 = (wave & 3) * RT, col0 = (wave >> 2) * CT;
+    const bool has_z = wave < J.MT, has_x = wave < J.KT;            // transposition duty: dZ tile `wave`, X tile `wave`
 
     Transposer<Mode> tr;
     tr.init(lane);
     f32x16 acc[RT][CT];
-    float bsum[RT];
+    float bsum = 0.0f;
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        bsum[i] = 0.0f;
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x16{};
-    }
+
     const int64_t per = (P.n_tiles32 + P.splits - 1) / P.splits;
     const int64_t t0 = split * per, t1 = (t0 + per < P.n_tiles32) ? t0 + per : P.n_tiles32;
     const char* xb = P.ctx + J.x_off + lane * 16;
     const char* zb = P.ctx + J.dz_off + lane * 16;
-    for (int64_t st = t0; st < t1; ++st) {
-        Act tz[RT], tx[CT];
+    const Act zero = Mode::template to_act<false>(f32x16{});
+    Act rz[ST], rx[ST];
+    auto fetch = [&](int64_t st0) {
 #pragma unroll
-        for (int i = 0; i < RT; ++i) {
-            if (row0 + i < J.MT) {
-                const f32x16 t = tr.run(IO::template load<Act>(zb + (st * J.MT + row0 + i) * (int64_t)TB));
+        for (int q = 0; q < ST; ++q) {
+            const bool in = st0 + q < t1;
+            rz[q] = (in && has_z) ? IO::template load<Act>(zb + ((st0 + q) * J.MT + wave) * (int64_t)TB) : zero;
+            rx[q] = (in && has_x) ? IO::template load<Act>(xb + ((st0 + q) * J.KT + wave) * (int64_t)TB) : zero;
+        }
+    };
+    if (t0 < t1) fetch(t0);
+    int buf = 0;
+    for (int64_t st0 = t0; st0 < t1; st0 += ST, buf ^= 1) {
+        char* stage = smem + buf * kStageBytes + lane * 16;
+        // transposition duty
+#pragma unroll
+        for (int q = 0; q < ST; ++q) {
+            if (has_z) {
+                const f32x16 t = tr.run(rz[q]);
                 float s = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += t[r];
-                bsum[i] += s;
-                tz[i] = Mode::template to_act<false>(t);
-            } else {
-                tz[i] = Mode::template to_act<false>(f32x16{});
+                bsum += s;
+                IO::store(stage + (q * 16 + wave) * TB, Mode::template to_act<false>(t));
+            }
+            if (has_x) IO::store(stage + (q * 16 + 8 + wave) * TB, Mode::template to_act<false>(tr.run(rx[q])));
+        }
+        if (st0 + ST < t1) fetch(st0 + ST);                       // next stage's saved tiles: in flight across the barrier and the MFMAs
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < ST; ++q) {
+            Act tz[RT];
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                if (row0 + i < J.MT) tz[i] = IO::template load<Act>(stage + (q * 16 + row0 + i) * TB);
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                if (col0 + j >= J.KT) continue;
+                const Act tx = IO::template load<Act>(stage + (q * 16 + 8 + col0 + j) * TB);
+#pragma unroll
+                for (int i = 0; i < RT; ++i)
+                    if (row0 + i < J.MT) OuterMma<Mode>::run(acc[i][j], tz[i], tx);
             }
         }
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-            if (col0 + j < J.KT) tx[j] = Mode::template to_act<false>(tr.run(IO::template load<Act>(xb + (st * J.KT + col0 + j) * (int64_t)TB)));
-            else tx[j] = Mode::template to_act<false>(f32x16{});
-        }
-#pragma unroll
-        for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j) OuterMma<Mode>::run(acc[i][j], tz[i], tx[j]);
     }
     // flush: accumulator tile rows = dZ features (registers), columns = X features (lanes)
     const int32_t* row_w = P.maps + J.map_off;
@@ -285,11 +307,11 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
                 if (w >= 0 && col >= 0) unsafeAtomicAdd(P.grad + w + col, acc[i][j][r]);
             }
         }
-        if (col0 == 0) {                              // one column group owns the bias sums
-            const float s = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-            const int b = row_b[32 * (row0 + i) + c];
-            if (h == 0 && b >= 0) unsafeAtomicAdd(P.grad + b, s);
-        }
+    }
+    if (has_z) {                                                   // bias: the wave that transposed dZ tile `wave` summed it
+        const float s = bsum + __shfl_xor(bsum, 32, 64);
+        const int b = row_b[32 * wave + c];
+        if (h == 0 && b >= 0) unsafeAtomicAdd(P.grad + b, s);
     }
 }
 

@@ -57,8 +57,14 @@ int run_train_backward(const DeviceNet& net, const TrainDev& t, int mode, TrainK
     return NRF_OK;
 }
 
-template <class Mode, int RT, int CT>
+template <class Mode, int ST>
 int run_weight_grad(const DeviceNet& net, const TrainDev& t, const TrainKArgs& k, float* grad, hipStream_t s, std::string& err) {
+    auto kernel = weight_grad_kernel<Mode, ST>;
+    constexpr int kLds = 2 * ST * 16 * tile_bytes<Mode>();
+    static_assert(kLds <= 160 * 1024, "weight-gradient staging exceeds the LDS");
+    static unsigned char done[64] = {};
+    const int prepared = prepare(kernel, net.device, done, err, kLds);
+    if (prepared != NRF_OK) return prepared;
     GradKArgs g{};
     g.ctx = k.ctx; g.grad = grad; g.maps = t.maps; g.n_jobs = t.n_jobs; g.n_tiles32 = tiles32(k.n);
     for (int j = 0; j < t.n_jobs; ++j) {
@@ -67,13 +73,14 @@ int run_weight_grad(const DeviceNet& net, const TrainDev& t, const TrainKArgs& k
         g.jobs[j].KT = t.job_KT[j]; g.jobs[j].MT = t.job_MT[j];
         g.jobs[j].map_off = j * kMapStride;
     }
-    constexpr int jobs_x = (8 + (RT * CT) - 1) / (RT * CT);        // == (8 + cgroups*CT - 1) / (cgroups*CT) with cgroups = RT
-    int64_t splits = (2 * (int64_t)net.cu_count + t.n_jobs * jobs_x - 1) / (t.n_jobs * jobs_x);
-    if (splits > g.n_tiles32) splits = g.n_tiles32;
+    // one workgroup per CU (128 KiB of LDS): about two rounds of workgroups, each with at least a few stages
+    int64_t splits = (2 * (int64_t)net.cu_count + t.n_jobs - 1) / t.n_jobs;
+    const int64_t max_splits = (g.n_tiles32 + 4 * ST - 1) / (4 * ST);
+    if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     g.splits = (int)splits;
-    const unsigned grid = (unsigned)(t.n_jobs * jobs_x * splits);
-    hipLaunchKernelGGL((weight_grad_kernel<Mode, RT, CT>), dim3(grid), dim3(512), 0, s, g);
+    const unsigned grid = (unsigned)(t.n_jobs * splits);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), kLds, s, g);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("weight gradient launch: ") + hipGetErrorString(e); return NRF_EHIP; }
     return NRF_OK;
@@ -124,9 +131,9 @@ int launch_train_backward(const DeviceNet& net, const TrainDev& t, int mode, con
     }
     if (r != NRF_OK) return r;
     switch (mode) {
-        case NRF_MMA_BF16: return run_weight_grad<ModeBF16, 2, 4>(net, t, k, grad, s, err);
-        case NRF_MMA_F16:  return run_weight_grad<ModeF16, 2, 4>(net, t, k, grad, s, err);
-        default:           return run_weight_grad<ModeF32, 1, 4>(net, t, k, grad, s, err);
+        case NRF_MMA_BF16: return run_weight_grad<ModeBF16, 2>(net, t, k, grad, s, err);
+        case NRF_MMA_F16:  return run_weight_grad<ModeF16, 2>(net, t, k, grad, s, err);
+        default:           return run_weight_grad<ModeF32, 1>(net, t, k, grad, s, err);
     }
 }
 

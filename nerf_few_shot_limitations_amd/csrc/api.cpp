@@ -192,7 +192,7 @@ int ensure_train(nrf_model* m) {
         std::copy(J.row_w.begin(), J.row_w.end(), maps.begin() + (size_t)j * nrf::kMapStride);
         std::copy(J.row_b.begin(), J.row_b.end(), maps.begin() + (size_t)j * nrf::kMapStride + 320);
         std::copy(J.col.begin(), J.col.end(), maps.begin() + (size_t)j * nrf::kMapStride + 640);
-        m->train.job_x_slot[j] = J.x_slot; m->train.job_dz_slot[j] = J.dz_slot; m->train.job_KT[j] = J.KT; m->train.job_MT[j] = J.MT;
+        m->train.job_x_slot[j] = J.x_slot; m->train.job_dz_slot[j] = J.dz_slot; m->train.job_KT[j] = J.KT; m->train.job_MT[j] = J.MT; m->train.job_x_first[j] = J.x_first;
     }
     NRF_HIP(hipMalloc((void**)&m->d_maps, maps.size() * sizeof(int32_t)));
     NRF_HIP(hipMemcpy(m->d_maps, maps.data(), maps.size() * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -506,6 +506,42 @@ int nrf_mlp_backward_v1(nrf_model* m, int mma_mode, const float* out4, const flo
         return fail(NRF_EINVAL, "backward weights of this mode are older than the parameters: call nrf_model_update_device (with this mode) first");
     std::string err;
     const int r = nrf::launch_train_backward(m->net, m->train, mma_mode, out4, g_out4, n, ctx, flat_grad, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_mlp_forward_train(nrf_model* m, int mma_mode, const float* positions, const float* directions, int64_t n, float* rgb, float* density,
+                          void* ctx, int64_t ctx_bytes, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n == 0) return NRF_OK;
+    if (!positions || !directions || !rgb || !density || !ctx) return fail(NRF_EINVAL, "null pointer");
+    if (m->arch.net != NRF_NET_V2) return fail(NRF_EUNSUPPORTED, "nrf_mlp_forward_train is built for NRF_NET_V2 (V1: nrf_mlp_forward_train_v1)");
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    const int rc = ensure_train(m);
+    if (rc != NRF_OK) return rc;
+    if (ctx_bytes < nrf::train_ctx_bytes(m->train, mma_mode, n)) return fail(NRF_EINVAL, "context buffer smaller than nrf_train_context_bytes");
+    std::string err;
+    const int r = nrf::launch_train_forward_v2(m->net, m->train, mma_mode, positions, directions, n, rgb, density, ctx, (hipStream_t)stream, err);
+    return r == NRF_OK ? NRF_OK : fail(r, err);
+}
+
+int nrf_mlp_backward(nrf_model* m, int mma_mode, const float* rgb, const float* density, const float* g_rgb, const float* g_density, int64_t n,
+                     void* ctx, int64_t ctx_bytes, float* flat_grad, void* stream) {
+    if (!m) return fail(NRF_EINVAL, "model is NULL");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n == 0) return NRF_OK;
+    if (!rgb || !density || !g_rgb || !g_density || !ctx || !flat_grad) return fail(NRF_EINVAL, "null pointer");
+    if (m->arch.net != NRF_NET_V2) return fail(NRF_EUNSUPPORTED, "nrf_mlp_backward is built for NRF_NET_V2 (V1: nrf_mlp_backward_v1)");
+    DeviceGuard guard(m->device);
+    if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
+    const int rc = ensure_train(m);
+    if (rc != NRF_OK) return rc;
+    if (ctx_bytes < nrf::train_ctx_bytes(m->train, mma_mode, n)) return fail(NRF_EINVAL, "context buffer smaller than nrf_train_context_bytes");
+    if (!m->bfresh[mma_mode])
+        return fail(NRF_EINVAL, "backward weights of this mode are older than the parameters: call nrf_model_update_device (with this mode) first");
+    std::string err;
+    const int r = nrf::launch_train_backward_v2(m->net, m->train, mma_mode, rgb, density, g_rgb, g_density, n, ctx, flat_grad, (hipStream_t)stream, err);
     return r == NRF_OK ? NRF_OK : fail(r, err);
 }
 

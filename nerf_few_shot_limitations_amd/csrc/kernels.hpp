@@ -83,7 +83,7 @@ struct TrainDev {
     int n_slots;
     int slot_tiles[kMaxSlots];  // feature tiles per saved-tensor slot
     int n_jobs;
-    int job_x_slot[kMaxJobs], job_dz_slot[kMaxJobs], job_KT[kMaxJobs], job_MT[kMaxJobs];
+    int job_x_slot[kMaxJobs], job_dz_slot[kMaxJobs], job_KT[kMaxJobs], job_MT[kMaxJobs], job_x_first[kMaxJobs];
     int64_t n_params;
 };
 
@@ -93,6 +93,10 @@ int launch_train_forward(const DeviceNet& net, const TrainDev& t, int mma_mode, 
 // dZ chain + weight gradients: grad (flat, n_params floats) += dL/dparams
 int launch_train_backward(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* out4, const float* g_out4, int64_t n,
                           void* ctx, float* grad, hipStream_t s, std::string& err);
+int launch_train_forward_v2(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* pos, const float* dir, int64_t n, float* rgb,
+                            float* density, void* ctx, hipStream_t s, std::string& err);
+int launch_train_backward_v2(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* rgb, const float* density,
+                             const float* g_rgb, const float* g_density, int64_t n, void* ctx, float* grad, hipStream_t s, std::string& err);
 int launch_repack(const float* flat, const int32_t* src, int64_t n_elems, int mma_mode, void* out, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
                 hipStream_t s);

@@ -305,27 +305,34 @@ PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin
 // ---------------------------------------------------------------------------
 // training path
 // ---------------------------------------------------------------------------
-// Saved-tensor slots (V1, n = n_layers):  0 = encoded input (KT0 tiles);  l = 1..n: output of layers.{l-1} after
-// ReLU (8 tiles);  n+l = dZ of layers.{l-1} (8 tiles);  2n+1 = dZ of the head [d rgb logits, d sigma] (1 tile).
+// Saved-tensor slots: train_impl.hpp (V1), train_v2_impl.hpp (V2).
 bool make_backward_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, NetPlan& plan, std::string& err) {
     plan = NetPlan();
-    if (a.net != NRF_NET_V1) { err = "the training path is built for V1 (nerf_model.NeRFMLP) only"; return false; }
+    if (a.net != NRF_NET_V1 && a.net != NRF_NET_V2) { err = "the training path is built for V1 (nerf_model.NeRFMLP) and V2 (DensityMLP + ColorMLP)"; return false; }
     if (a.hidden != 256 || (int)lin.size() != expected_linears(a)) { err = "backward plan: unexpected architecture"; return false; }
     const int n = a.n_layers, H = a.hidden, HT = H / 32;
-    auto rows_all = [&]() { std::vector<int> r(H); for (int i = 0; i < H; ++i) r[i] = i; return r; };
-    {   // head^T: K = [rgb_out rows 0..2, sigma_out row 0] -> dH_n
-        LayerPlan L; L.transposed = true; L.KT = 1; L.MT = HT; L.krow.assign(32, {-1, 0});
+    auto first_cols = [&](int count, int MT) { std::vector<int> r(32 * MT, -1); for (int i = 0; i < count; ++i) r[i] = i; return r; };
+    auto transposed = [&](int li, int out_rows, int KT, int in_cols, int MT) {      // lin[li]^T: K = its rows, outputs = its first in_cols columns
+        LayerPlan L; L.transposed = true; L.KT = KT; L.MT = MT; L.krow.assign(32 * KT, {-1, 0});
+        for (int k = 0; k < out_rows; ++k) L.krow[k] = {li, k};
+        L.rcol = first_cols(in_cols, MT);
+        return L;
+    };
+    if (a.net == NRF_NET_V1) {
+        LayerPlan L; L.transposed = true; L.KT = 1; L.MT = HT; L.krow.assign(32, {-1, 0});        // head^T: K = [rgb_out rows 0..2, sigma_out row 0]
         for (int c = 0; c < 3; ++c) L.krow[c] = {n + 1, c};
         L.krow[3] = {n, 0};
-        L.rcol = rows_all();
+        L.rcol = first_cols(H, HT);
         plan.layers.push_back(std::move(L));
+    } else {
+        plan.layers.push_back(transposed(n + 4, 3, 1, H / 4, H / 128));         // color_layers.4^T: 3 -> 64
+        plan.layers.push_back(transposed(n + 3, H / 4, H / 128, H / 2, H / 64));   // color_layers.2^T: 64 -> 128
+        plan.layers.push_back(transposed(n + 2, H / 2, H / 64, H, HT));         // color_layers.0^T, feature columns only: 128 -> 256
+        LayerPlan FD = transposed(n + 1, H, HT + 1, H, HT);                     // [feature_head | density_head]^T: 256 + 1 -> 256
+        FD.krow[H] = {n, 0};
+        plan.layers.push_back(std::move(FD));
     }
-    for (int l = n - 1; l >= 1; --l) {   // layers.l^T: dZ of layers.l -> dH of layers.{l-1}
-        LayerPlan L; L.transposed = true; L.KT = HT; L.MT = HT; L.krow.resize(H);
-        for (int k = 0; k < H; ++k) L.krow[k] = {l, k};
-        L.rcol = rows_all();
-        plan.layers.push_back(std::move(L));
-    }
+    for (int l = n - 1; l >= 1; --l) plan.layers.push_back(transposed(l, H, HT, H, HT));   // trunk layer l^T: dZ_l -> dH_{l-1}
     int off = 0;
     for (auto& L : plan.layers) { L.bias_off = off; off += 32 * L.MT; }
     plan.n_bias = off;
@@ -334,31 +341,47 @@ bool make_backward_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, N
 
 bool make_train_plan(const nrf_arch& a, const NetPlan& fwd, const ParamLayout& lay, TrainPlan& tp, std::string& err) {
     tp = TrainPlan();
-    if (a.net != NRF_NET_V1) { err = "the training path is built for V1 (nerf_model.NeRFMLP) only"; return false; }
+    if (a.net != NRF_NET_V1 && a.net != NRF_NET_V2) { err = "the training path is built for V1 and V2"; return false; }
     const int n = a.n_layers;
-    if ((int)fwd.layers.size() != n + 1) { err = "train plan: forward plan has an unexpected layer count"; return false; }
-    tp.slot_tiles.assign(2 * n + 2, 8);
-    tp.slot_tiles[0] = fwd.layers[0].KT;
-    tp.slot_tiles[2 * n + 1] = 1;
-    for (int l = 0; l <= n; ++l) {
-        const LayerPlan& L = fwd.layers[l];
+    const int expect = a.net == NRF_NET_V1 ? n + 1 : n + 5;
+    if ((int)fwd.layers.size() != expect) { err = "train plan: forward plan has an unexpected layer count"; return false; }
+    // one job per forward-plan layer (a window of <= 8 input tiles of it)
+    auto add_job = [&](const LayerPlan& L, int x_slot, int dz_slot, int x_first, int KT, bool with_bias) {
         GradJobPlan J;
-        J.x_slot = l; J.dz_slot = l < n ? n + 1 + l : 2 * n + 1; J.KT = L.KT; J.MT = L.MT;
+        J.x_slot = x_slot; J.dz_slot = dz_slot; J.KT = KT; J.MT = L.MT; J.x_first = x_first;
         J.row_w.assign(32 * L.MT, -1); J.row_b.assign(32 * L.MT, -1);
         std::vector<std::pair<int, int>> seen;
         for (int r = 0; r < 32 * L.MT; ++r) {
             const auto& rs = L.row[r];
             if (rs.first < 0) continue;
-            bool dup = false;                   // the head tile repeats its rows for the second lane half: count once
+            bool dup = false;                   // head tiles repeat their rows for the second lane half: count once
             for (const auto& q : seen) dup = dup || q == rs;
             if (dup) continue;
             seen.push_back(rs);
             J.row_w[r] = (int32_t)(lay.w_off[rs.first] + (int64_t)rs.second * lay.in_f[rs.first]);
-            J.row_b[r] = (int32_t)(lay.b_off[rs.first] + rs.second);
+            if (with_bias) J.row_b[r] = (int32_t)(lay.b_off[rs.first] + rs.second);
         }
-        J.col.assign(L.col.begin(), L.col.end());
+        J.col.assign(L.col.begin() + 32 * x_first, L.col.begin() + 32 * (x_first + KT));
         tp.jobs.push_back(std::move(J));
+    };
+    if (a.net == NRF_NET_V1) {
+        tp.slot_tiles.assign(2 * n + 2, 8);
+        tp.slot_tiles[0] = fwd.layers[0].KT;
+        tp.slot_tiles[2 * n + 1] = 1;
+        for (int l = 0; l <= n; ++l) add_job(fwd.layers[l], l, l < n ? n + 1 + l : 2 * n + 1, 0, fwd.layers[l].KT, true);
+        return true;
     }
+    tp.slot_tiles.assign(2 * n + 9, 8);
+    tp.slot_tiles[0] = fwd.layers[0].KT;
+    tp.slot_tiles[n + 1] = 9; tp.slot_tiles[n + 2] = 4; tp.slot_tiles[n + 3] = 2;
+    tp.slot_tiles[2 * n + 4] = 1; tp.slot_tiles[2 * n + 6] = 4; tp.slot_tiles[2 * n + 7] = 2; tp.slot_tiles[2 * n + 8] = 1;
+    for (int l = 0; l < n; ++l) add_job(fwd.layers[l], l, n + 4 + l, 0, fwd.layers[l].KT, true);
+    add_job(fwd.layers[n], n, 2 * n + 4, 0, 8, true);              // density_head
+    add_job(fwd.layers[n + 1], n, 2 * n + 5, 0, 8, true);          // feature_head
+    add_job(fwd.layers[n + 2], n + 1, 2 * n + 6, 0, 8, true);      // color_layers.0, feature columns
+    add_job(fwd.layers[n + 2], n + 1, 2 * n + 6, 8, 1, false);     // color_layers.0, direction-encoding columns (bias counted above)
+    add_job(fwd.layers[n + 3], n + 2, 2 * n + 7, 0, 4, true);      // color_layers.2
+    add_job(fwd.layers[n + 4], n + 3, 2 * n + 8, 0, 2, true);      // color_layers.4
     return true;
 }
 

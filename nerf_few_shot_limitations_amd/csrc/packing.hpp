@@ -60,7 +60,7 @@ std::vector<int32_t> bias_sources(const NetPlan& plan, const ParamLayout& lay);
 // One weight-gradient job = one Linear (or the head pseudo-layer): dW[o][i] += sum_samples dZ[o] * X[i].
 // Saved-tensor slots: train_impl.hpp.
 struct GradJobPlan {
-    int x_slot = 0, dz_slot = 0, KT = 0, MT = 0;
+    int x_slot = 0, dz_slot = 0, KT = 0, MT = 0, x_first = 0;
     std::vector<int32_t> row_w, row_b;           // 32*MT: flat offset of the weight row / of the bias, -1 = none
     std::vector<int32_t> col;                    // 32*KT: column inside the weight row, -1 = none
 };

@@ -21,15 +21,51 @@ namespace nrf {
 
 struct TrainKArgs {
     NetArgs net;              // forward: forward stream + bias table; backward: the transposed stream
-    const float* x_enc;       // (P, pe_dim)
+    const float* x_enc;       // V1: (P, pe_dim)
+    const float* pos;         // V2: (P,3)
+    const float* dir;         // V2: (P,3)
     int64_t n;                // samples
     int64_t n_tiles;          // workgroup tiles of WAVES*32 samples
-    float* out4;              // forward: (P,4) written; backward: the same tensor, read (sigmoid')
-    const float* g_out4;      // backward: dL/d out4 (P,4)
+    float* out4;              // V1 forward: (P,4) written; backward: the same tensor, read (sigmoid')
+    const float* g_out4;      // V1 backward: dL/d out4 (P,4)
+    float* rgb;               // V2: (P,3) written by forward, read by backward
+    float* density;           // V2: (P,1)
+    const float* g_rgb;       // V2 backward: dL/d rgb (P,3)
+    const float* g_density;   // V2 backward: dL/d density (P,1)
     char* ctx;                // saved tensors
     int64_t slot_off[kMaxSlots];
     int slot_tiles[kMaxSlots];
 };
+
+// ---- host-side helpers shared by train_v1.hip / train_v2.hip -------------------------------------------------
+constexpr int kWgSamples = 256;          // the context is laid out for whole 256-sample groups, whatever the geometry
+
+inline int64_t tiles32(int64_t n) { return (n + kWgSamples - 1) / kWgSamples * (kWgSamples / 32); }
+
+inline int tile_bytes_of(int mode) { return mode == NRF_MMA_F32 ? 4 * kFragBytes : 2 * kFragBytes; }
+
+inline bool fill_slots(const TrainDev& t, int mode, int64_t n, TrainKArgs& k, std::string& err) {
+    if (t.n_slots < 1 || t.n_slots > kMaxSlots) { err = "training plan missing"; return false; }
+    const int64_t nt = tiles32(n);
+    int64_t off = 0;
+    for (int i = 0; i < t.n_slots; ++i) {
+        k.slot_off[i] = off;
+        k.slot_tiles[i] = t.slot_tiles[i];
+        off += nt * t.slot_tiles[i] * tile_bytes_of(mode);
+    }
+    return true;
+}
+
+inline bool check_train_common(const DeviceNet& net, const TrainDev& t, int mode, std::string& err) {
+    if (mode < 0 || mode > 2) { err = "unknown mma_mode"; return false; }
+    if (net.arch.pos_freq != 10) { err = "the training path is built for pos_freq 10"; return false; }
+    if (!t.bstream[mode] || !t.maps) { err = "model not prepared for training"; return false; }
+    if (net.n_bias > kBiasMaxFloats) { err = "bias table exceeds the LDS carve-out"; return false; }
+    return true;
+}
+
+// dW/db of every Linear from the saved tensors (defined in train_v1.hip; network independent)
+int launch_weight_grad(const DeviceNet& net, const TrainDev& t, int mode, const TrainKArgs& k, float* grad, hipStream_t s, std::string& err);
 
 template <class Mode>
 __device__ __forceinline__ char* tile_ptr(const TrainKArgs& P, int slot, int64_t st, int t, int lane) {
@@ -195,9 +231,10 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_kernel(const TrainK
 // ---------------------------------------------------------------------------------------------
 struct GradJob {
     int64_t x_off, dz_off;      // slot bases inside the context
-    int KT, MT;                 // feature tiles of X / of dZ
+    int KT, MT;                 // feature tiles of X / of dZ used by this job
+    int x_stride, dz_stride;    // feature tiles per sample tile of the two slots
+    int x_first;                // first X tile of the window (a Linear fed by a concatenation is split into windows of <= 8 tiles)
     int map_off;                // this job's row_w | row_b | col tables inside `maps` (ints)
-    int pad;
 };
 
 struct GradKArgs {
@@ -250,8 +287,8 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
 #pragma unroll
         for (int q = 0; q < ST; ++q) {
             const bool in = st0 + q < t1;
-            rz[q] = (in && has_z) ? IO::template load<Act>(zb + ((st0 + q) * J.MT + wave) * (int64_t)TB) : zero;
-            rx[q] = (in && has_x) ? IO::template load<Act>(xb + ((st0 + q) * J.KT + wave) * (int64_t)TB) : zero;
+            rz[q] = (in && has_z) ? IO::template load<Act>(zb + ((st0 + q) * J.dz_stride + wave) * (int64_t)TB) : zero;
+            rx[q] = (in && has_x) ? IO::template load<Act>(xb + ((st0 + q) * J.x_stride + J.x_first + wave) * (int64_t)TB) : zero;
         }
     };
     if (t0 < t1) fetch(t0);
@@ -312,44 +349,6 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
         const float s = bsum + __shfl_xor(bsum, 32, 64);
         const int b = row_b[32 * wave + c];
         if (h == 0 && b >= 0) unsafeAtomicAdd(P.grad + b, s);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// parameter re-pack and Adam
-// ---------------------------------------------------------------------------------------------
-// out element i = convert(flat[src[i]]) (0 where src < 0); mode selects the operand type
-__global__ void __launch_bounds__(256) repack16_kernel(const float* __restrict__ flat, const int32_t* __restrict__ src, int64_t n_pairs,
-                                                      int bf16, uint32_t* __restrict__ out) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
-        const int2 s = *(const int2*)(src + 2 * i);
-        const float a = s.x >= 0 ? flat[s.x] : 0.0f, b = s.y >= 0 ? flat[s.y] : 0.0f;
-        out[i] = bf16 ? (uint32_t)pack_pair<bf16x2, false>(a, b) : (uint32_t)pack_pair<f16x2, false>(a, b);
-    }
-}
-
-__global__ void __launch_bounds__(256) repack32_kernel(const float* __restrict__ flat, const int32_t* __restrict__ src, int64_t n,
-                                                      float* __restrict__ out) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int s = src[i];
-        out[i] = s >= 0 ? flat[s] : 0.0f;
-    }
-}
-
-// torch.optim.Adam (train.py:113-118; no amsgrad, weight decay added to the gradient, bias-corrected moments):
-//   g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
-__global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                  float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                  float wd, float bc1, float bc2_sqrt) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float gi = g[i];
-        const float pi = p[i];
-        if (wd != 0.0f) gi = __fadd_rn(gi, __fmul_rn(wd, pi));
-        const float mi = __fadd_rn(__fmul_rn(b1, m[i]), __fmul_rn(1.0f - b1, gi));
-        const float vi = __fadd_rn(__fmul_rn(b2, v[i]), __fmul_rn(__fmul_rn(1.0f - b2, gi), gi));
-        m[i] = mi; v[i] = vi;
-        const float denom = __fadd_rn(sqrtf(vi) / bc2_sqrt, eps);
-        p[i] = __fsub_rn(pi, __fmul_rn(lr / bc1, mi / denom));
     }
 }
 

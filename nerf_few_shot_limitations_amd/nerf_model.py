@@ -8,9 +8,9 @@ Two constructor forms, as the reference uses them:
             (positions (P,3), directions (P,3), dino (P,C)|None) -> (rgb (P,3), density (P,1))
             src/training/train.py:82-89,229; the module tree mirrors
             src/models/nerf_mlp.py:86-158 (NeRFWithDINO) so checkpoints load by name.
-With grad enabled the legacy (V1) form runs the training kernels (training.py: saved
-activations, transposed-stream backward, MFMA weight gradients); the trainer forms (V2/V3)
-are inference only and a grad-enabled call raises instead of silently detaching.
+With grad enabled the legacy (V1) form and the trainer form without DINO (V2) run the training
+kernels (training.py: saved activations, transposed-stream backward, MFMA weight gradients); the
+DINO form (V3) is inference only and a grad-enabled call raises instead of silently detaching.
 """
 from __future__ import annotations
 
@@ -210,11 +210,12 @@ class NeRFMLP(nn.Module):
 
     def forward(self, positions, directions=None, dino_features=None):
         if self._wants_grad():
-            if self.net != L.NRF_NET_V1:
-                raise NotImplementedError("the backward of the HIP path is built for the legacy NeRFMLP(pos_dim=63) form only "
-                                          "(SURVEY.md section 8 f1); call the trainer forms under torch.no_grad().")
-            from .training import mlp_v1_train
-            return mlp_v1_train(self, positions)
+            if self.net == L.NRF_NET_V3:
+                raise NotImplementedError("the backward of the HIP path is built for the legacy NeRFMLP(pos_dim=63) form and for the "
+                                          "trainer form with use_dino=False (SURVEY.md section 8 f1); call a use_dino=True model under "
+                                          "torch.no_grad().")
+            from .training import mlp_v1_train, mlp_v2_train
+            return mlp_v1_train(self, positions) if self.net == L.NRF_NET_V1 else mlp_v2_train(self, positions, directions)
         mode = L.MMA_MODES[self.mma_mode]
         x = L.dev_f32(positions)
         h = self.handle(x.device)

@@ -115,6 +115,55 @@ class _MLPV1Fn(torch.autograd.Function):
         return (None, None, *fp.views(grad))
 
 
+class _MLPV2Fn(torch.autograd.Function):
+    """nerf_mlp.py:134-158 without the DINO branch: (positions, directions) -> (rgb, density)."""
+
+    @staticmethod
+    def forward(ctx, module, pos, dirs, *params):
+        dev = pos.device
+        h, mode = _train_handle(module, dev)
+        n = pos.shape[0]
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        dens = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = L.lib().nrf_train_context_bytes(h, mode, n)
+            if nbytes < 0:
+                raise L.NrfError(-2, L.lib().nrf_last_error().decode("utf-8", "replace"))
+            buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+            L.check(L.lib().nrf_mlp_forward_train(h, mode, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(dens), C.c_void_p(buf.data_ptr()), nbytes,
+                                                  L.stream_ptr()))
+        ctx.module, ctx.buf, ctx.nbytes, ctx.n, ctx.mode = module, buf, nbytes, n, mode
+        ctx.versions = module._versions()
+        ctx.save_for_backward(rgb, dens)
+        return rgb, dens
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_dens):
+        module = ctx.module
+        if module._versions() != ctx.versions:
+            raise RuntimeError("NeRFMLP parameters were modified between forward and backward: the saved activations "
+                               "no longer match the packed weights")
+        rgb, dens = ctx.saved_tensors
+        dev = rgb.device
+        g_rgb = g_rgb.to(torch.float32).contiguous()
+        g_dens = g_dens.to(torch.float32).contiguous()
+        fp = module.flat_params()
+        grad = torch.zeros_like(fp.flat)
+        with torch.cuda.device(dev):
+            L.check(L.lib().nrf_mlp_backward(module._handle, ctx.mode, L.ptr(rgb), L.ptr(dens), L.ptr(g_rgb), L.ptr(g_dens), ctx.n,
+                                             C.c_void_p(ctx.buf.data_ptr()), ctx.nbytes, L.ptr(grad), L.stream_ptr()))
+        ctx.buf = None
+        return (None, None, None, *fp.views(grad))
+
+
+def mlp_v2_train(module, positions, directions):
+    """(P,3) positions, (P,3) directions -> rgb (P,3), density (P,1), differentiable with respect to the parameters."""
+    pos = L.dev_f32(positions).reshape(-1, 3)
+    dirs = L.dev_f32(directions, pos.device).reshape(-1, 3)
+    module.flat_params().ensure()
+    return _MLPV2Fn.apply(module, pos, dirs, *module.flat_params().params())
+
+
 def mlp_v1_train(module, x_enc):
     """(P, 63) encoded points -> (P, 4) = [sigmoid rgb, raw sigma], differentiable with respect to the parameters."""
     x = L.dev_f32(x_enc)

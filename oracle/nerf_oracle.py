@@ -535,3 +535,31 @@ def mlp_v1_train_emulated(p: Dict[str, torch.Tensor], x_enc: torch.Tensor, g_out
         if i > 0:
             dh = dz @ q(p[f"layers.{i}.weight"])
     return out, grads, h, dzs[::-1] + [d_head]
+
+
+def relu_margin(p: Dict[str, torch.Tensor], variant: str, x, directions=None) -> torch.Tensor:
+    """Per sample, the smallest |pre-activation| over every ReLU of the network ('v1': x = encoded points; 'v2':
+    x = positions).  A sample whose margin is within summation-order noise of 0 has an ill-defined ReLU mask: its
+    gradient legitimately differs between any two correct implementations (tests exclude such samples)."""
+    def stack(prefix, h, step):
+        m = torch.full((h.shape[0],), float("inf"))
+        i = 0
+        while f"{prefix}{i}.weight" in p:
+            z = _lin(p, f"{prefix}{i}", h)
+            m = torch.minimum(m, z.abs().amin(-1))
+            h = F.relu(z)
+            i += step
+        return h, m
+    if variant == "v1":
+        return stack("layers.", x, 1)[1]
+    pe = positional_encoding(x, 10)
+    h, m = stack("density_mlp.density_layers.", pe, 2)
+    dens = _lin(p, "density_mlp.density_head", h)
+    feat = _lin(p, "density_mlp.feature_head", h)
+    m = torch.minimum(m, dens.abs().amin(-1))
+    c = torch.cat([feat, positional_encoding(directions, 4)], -1)
+    for i in (0, 2):
+        z = _lin(p, f"color_mlp.color_layers.{i}", c)
+        m = torch.minimum(m, z.abs().amin(-1))
+        c = F.relu(z)
+    return m

@@ -276,10 +276,15 @@ def test_model_update_repacks(N, golden):
     assert maxdiff(b[:, :3], golden("mlp_v1_solid")["out"][:, :3]) <= 1e-5
 
 
-def test_forward_is_inference_only(N):
+def test_forward_under_grad_is_differentiable_or_refuses(N):
+    """V1/V2 run the training kernels under grad (tests/test_gpu_training.py); the DINO form has no backward and must
+    refuse instead of silently detaching; the fused renderer is inference only."""
     m, _ = model_v1(N)
+    out = m(torch.zeros(4, 63).cuda())
+    assert out.requires_grad and out.grad_fn is not None
+    m3, _ = model_v3(N)
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(4, 63))
+        m3(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 64).cuda())
 
 
 # ------------------------------------------------------------------ a11 fused renderer vs golden (reference outputs)

@@ -43,6 +43,12 @@ def inputs(n, seed=3):
     return x, g
 
 
+# Samples with a ReLU pre-activation closer to 0 than this get no incoming gradient in the fp32-mode comparisons: their
+# mask is decided by summation order (and, for V2, by the last bit of sin/cos), and one flipped mask changes the sample's
+# whole gradient below it -- on either side of the comparison (oracle.relu_margin).
+MARGIN = 2e-5
+
+
 def rel_to_max(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
@@ -238,6 +244,7 @@ def test_saved_tensors_stage_consistent_16bit(N, mode):
 def test_gradients_fp32_mode_match_autograd(N, n):
     model, p = make_model(N, "f32", scene="solid")
     x, g = inputs(n, seed=11)
+    g = g * (O.relu_margin(p, "v1", x) > MARGIN)[:, None]
     _, grad, _ = run_raw(N, model, x, g)
     pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     (O.mlp_v1(pp, x) * g).sum().backward()
@@ -277,6 +284,7 @@ def test_backward_accumulates_into_the_gradient_vector(N):
 def test_other_depths(N, n_layers):
     model, p = make_model(N, "f32", n_layers=n_layers)
     x, g = inputs(700, seed=31)
+    g = g * (O.relu_margin(p, "v1", x) > MARGIN)[:, None]
     _, grad, _ = run_raw(N, model, x, g)
     pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     (O.mlp_v1(pp, x) * g).sum().backward()
@@ -439,7 +447,104 @@ def test_fused_adam_loop_reduces_loss(N):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
-def test_forward_with_grad_refuses_trainer_forms(N):
-    m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False).cuda().train()
+def test_forward_with_grad_refuses_the_dino_form(N):
+    m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64).cuda().train()
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda())
+        m(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 64).cuda())
+
+
+# ---------------------------------------------------------------------------------------------
+# V2: the network train.py builds (use_dino=False)
+# ---------------------------------------------------------------------------------------------
+def make_v2(N, mode, scene="fog", n_layers=8, seed=1):
+    m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=n_layers, use_dino=False, mma_mode=mode)
+    p = O.make_weights("v2", seed, scene, n_layers=n_layers)
+    m.load_state_dict(p, strict=False)
+    return m.cuda().train(), p
+
+
+def v2_inputs(n, seed=5):
+    pos = torch.from_numpy(O.uniform01(seed, n * 3).reshape(n, 3) * 4 - 2).float()
+    dirs = torch.from_numpy(O.uniform01(seed + 1, n * 3).reshape(n, 3) * 2 - 1).float()
+    g_rgb = torch.from_numpy(O.uniform01(seed + 2, n * 3).reshape(n, 3) - 0.5).float()
+    g_den = torch.from_numpy(O.uniform01(seed + 3, n).reshape(n, 1) - 0.5).float()
+    return pos, dirs, g_rgb, g_den
+
+
+def v2_grads(model):
+    return {name: p.grad for name, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("n,n_layers", [(1000, 8), (257, 8), (4096 + 17, 8), (600, 3), (600, 2)])
+def test_v2_gradients_fp32_mode_match_autograd(N, n, n_layers):
+    model, p = make_v2(N, "f32", scene="solid", n_layers=n_layers)
+    pos, dirs, g_rgb, g_den = v2_inputs(n)
+    keep = (O.relu_margin(p, "v2", pos, dirs) > MARGIN)[:, None]
+    assert keep.float().mean() > 0.9
+    g_rgb, g_den = g_rgb * keep, g_den * keep
+    rgb, den = model(pos.cuda(), dirs.cuda())
+    ((rgb * g_rgb.cuda()).sum() + (den * g_den.cuda()).sum()).backward()
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    o_rgb, o_den = O.mlp_v2(pp, pos, dirs)
+    assert (rgb.detach().cpu() - o_rgb.detach()).abs().max() < 1e-4 and rel_to_max(den, o_den) < 1e-4
+    ((o_rgb * g_rgb).sum() + (o_den * g_den).sum()).backward()
+    checked = 0
+    for name, g in v2_grads(model).items():
+        if name in pp:
+            assert rel_to_max(g, pp[name].grad) < 2e-4, name
+            checked += 1
+    assert checked == 2 * (n_layers + 5)
+
+
+@pytest.mark.parametrize("mode,cos_min", [("bf16", 0.97), ("f16", 0.995)])
+def test_v2_gradients_16bit_modes_vs_fp32_autograd(N, mode, cos_min):
+    n = 3000
+    model, p = make_v2(N, mode)
+    pos, dirs, g_rgb, g_den = v2_inputs(n, seed=15)
+    rgb, den = model(pos.cuda(), dirs.cuda())
+    ((rgb * g_rgb.cuda()).sum() + (den * g_den.cuda()).sum()).backward()
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    o_rgb, o_den = O.mlp_v2(pp, pos, dirs)
+    ((o_rgb * g_rgb).sum() + (o_den * g_den).sum()).backward()
+    for name, g in v2_grads(model).items():
+        if name in pp and name.endswith("weight"):
+            assert cosine(g, pp[name].grad) > cos_min, (name, cosine(g, pp[name].grad))
+
+
+def test_v2_train_step_as_train_py_runs_it(N):
+    """train.py:188-242,280-288 on the drop-in surface: sample -> model(pts, dirs) -> VolumeRenderer -> mse on 'rgb' ->
+    backward -> Adam; three steps in fp32 mode against the same loop on the CPU oracle."""
+    R, S, steps = 96, 24, 3
+    c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
+    ro, rd = O.get_rays(16, 16, O.focal_for(16), c2w)
+    ro, rd = ro.reshape(-1, 3)[:R], rd.reshape(-1, 3)[:R]
+    t_rand = torch.from_numpy(O.uniform01(7, R * S).reshape(R, S)).float()
+    pts, z = O.sample_points_along_rays(ro, rd, 2.0, 6.0, S, t_rand)
+    dirs = rd[:, None, :].expand(R, S, 3).reshape(-1, 3)                      # train.py:225: raw ray directions per sample
+    target = torch.from_numpy(O.uniform01(8, R * 3).reshape(R, 3)).float()
+    p = O.make_weights("v2", 1, "solid")
+    pp = {k: torch.nn.Parameter(v.clone()) for k, v in p.items()}
+    opt = torch.optim.Adam(list(pp.values()), lr=5e-4, weight_decay=1e-6)       # baseline.yaml:39-40
+    cpu_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        rgb, den = O.mlp_v2(pp, pts.reshape(-1, 3), dirs)
+        pred = O.volume_render(rgb.reshape(R, S, 3), den.reshape(R, S, 1), z, rd)[0]
+        loss = torch.nn.functional.mse_loss(pred, target)
+        loss.backward()
+        opt.step()
+        cpu_losses.append(loss.item())
+    model, _ = make_v2(N, "f32", scene="solid")
+    vr = N.VolumeRenderer()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=1e-6)
+    ptsd, dirsd, zd, rdd, td = pts.reshape(-1, 3).cuda(), dirs.cuda(), z.cuda(), rd.cuda(), target.cuda()
+    gpu_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        rgb, den = model(ptsd, dirsd, None)
+        pred, _, _ = vr(rgb.reshape(R, S, 3), den.reshape(R, S, 1), zd, rdd)
+        loss = torch.nn.functional.mse_loss(pred, td)
+        loss.backward()
+        opt.step()
+        gpu_losses.append(loss.item())
+    assert np.allclose(cpu_losses, gpu_losses, rtol=2e-4, atol=1e-6), (cpu_losses, gpu_losses)

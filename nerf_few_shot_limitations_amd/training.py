@@ -241,6 +241,20 @@ class Adam:
             self.exp_avg_sq = torch.zeros_like(flat)
         return fp, flat
 
+    @staticmethod
+    def _flat_grad_of(ps, fp, flat):
+        """The one vector all .grad tensors are views of, if they are (the backward of training.py hands out views of its
+        flat gradient in exactly this layout and autograd keeps them when nothing else accumulated)."""
+        g0 = ps[0].grad
+        base = getattr(g0, "_base", None) if g0 is not None else None
+        if base is None or base.shape != flat.shape or base.dtype != torch.float32 or base.device != flat.device or not base.is_contiguous():
+            return None
+        b = base.data_ptr()
+        for p, off in zip(ps, fp.offsets):
+            if p.grad is None or p.grad.data_ptr() != b + 4 * off:
+                return None
+        return base
+
     def zero_grad(self, set_to_none=True):
         for p in self.module.flat_params().params():
             if set_to_none:
@@ -251,18 +265,112 @@ class Adam:
     def step(self):
         fp, flat = self._buffers()
         ps = fp.params()
-        # gather the gradients autograd left on the parameters into the flat layout (a no-op copy when they already are views of one vector)
-        g = self.grad if self.grad is not None and self.grad.shape == flat.shape and self.grad.device == flat.device else torch.empty_like(flat)
-        self.grad = g
-        gv = fp.views(g)
-        with torch.no_grad():
-            for p, v in zip(ps, gv):
-                if p.grad is None:
-                    v.zero_()
-                elif p.grad.data_ptr() != v.data_ptr():
-                    v.copy_(p.grad)
+        g = self._flat_grad_of(ps, fp, flat)
+        if g is None:
+            # gather the gradients autograd left on the parameters into the flat layout
+            g = self.grad if self.grad is not None and self.grad.shape == flat.shape and self.grad.device == flat.device else torch.empty_like(flat)
+            self.grad = g
+            with torch.no_grad():
+                for p, v in zip(ps, fp.views(g)):
+                    if p.grad is None:
+                        v.zero_()
+                    elif p.grad.data_ptr() != v.data_ptr():
+                        v.copy_(p.grad)
         self.step_count += 1
         with torch.no_grad(), torch.cuda.device(flat.device):
             L.check(L.lib().nrf_adam_step(L.ptr(flat), L.ptr(g), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), flat.numel(), self.lr,
                                           self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count, L.stream_ptr()))
         self.module._gen += 1            # the packed streams are now older than the parameters
+
+
+# ---------------------------------------------------------------------------------------------
+# one optimisation step without autograd in between
+# ---------------------------------------------------------------------------------------------
+class FusedStep:
+    """The body of the reference's inner loop -- render a batch of rays, `rgb_weight * mse(pred['rgb'], target)`
+    (train.py:36-44,280-288; train_minimal.py:102-123), backward, Adam -- as a fixed sequence of libnerfhip calls on
+    preallocated buffers: saving forward -> composite -> d(mse) -> composite backward -> dZ chain + weight gradients ->
+    Adam -> (next step) device re-pack.  Same kernels and the same numbers as the autograd route; what it saves is the
+    autograd graph, the per-parameter gradient tensors and the Python between the launches, which at the reference's batch
+    sizes (1-2 k rays x 32-64 samples) cost more than the kernels.
+
+        step = FusedStep(model, lr=5e-4, weight_decay=1e-6)
+        loss = step(points, z_vals, rays_d, target)               # V1: points = encoded (R*S, 63)
+        loss = step(points, z_vals, rays_d, target, dirs=dirs)    # V2: points (R*S, 3), dirs (R*S, 3)
+    """
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, rgb_weight=1.0, white_bkgd=False):
+        if model.net not in (L.NRF_NET_V1, L.NRF_NET_V2):
+            raise NotImplementedError("FusedStep: V1 and V2 models only")
+        self.model = model
+        self.opt = Adam(model, lr, betas, eps, weight_decay)
+        self.rgb_weight = float(rgb_weight)
+        self.white = int(bool(white_bkgd))
+        self._key = None
+
+    def _buffers(self, n, R, S, dev, h, mode):
+        key = (n, R, S, str(dev), mode)
+        if self._key != key:
+            nbytes = L.lib().nrf_train_context_bytes(h, mode, n)
+            if nbytes < 0:
+                raise L.NrfError(-2, L.lib().nrf_last_error().decode("utf-8", "replace"))
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+            self.ctx = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+            self.nbytes = nbytes
+            self.out4, self.d_out4 = f(n, 4), f(n, 4)                 # V1: [rgb, sigma] rows; V2: rgb | density packed in the same rows
+            self.pred, self.g_pred = f(R, 3), f(R, 3)
+            self.grad = torch.zeros(self.model.flat_params().flat.numel(), dtype=torch.float32, device=dev)
+            self._key = key
+
+    @torch.no_grad()
+    def __call__(self, points, z_vals, rays_d, target, dirs=None):
+        m = self.model
+        pts = L.dev_f32(points)
+        dev = pts.device
+        z = L.dev_f32(z_vals, dev)
+        R, S = z.shape
+        d = L.dev_f32(rays_d, dev).reshape(R, 3)
+        tgt = L.dev_f32(target, dev).reshape(R, 3)
+        v2 = m.net == L.NRF_NET_V2
+        pts = pts.reshape(R * S, 3 if v2 else 3 * (2 * m.pos_freq + 1))
+        n = R * S
+        lib = L.lib()
+        h, mode = _train_handle(m, dev)
+        with torch.cuda.device(dev):
+            self._buffers(n, R, S, dev, h, mode)
+            st = L.stream_ptr()
+            ctx = C.c_void_p(self.ctx.data_ptr())
+            o4, d4 = self.out4, self.d_out4
+            if v2:
+                # rgb -> columns 0..2 of the first 3n/4 rows' worth of storage is not strided: keep two plain tensors as views
+                rgb, den = o4.view(-1)[:3 * n].view(n, 3), o4.view(-1)[3 * n:].view(n, 1)
+                g_rgb, g_den = d4.view(-1)[:3 * n].view(n, 3), d4.view(-1)[3 * n:].view(n, 1)
+                dirs_d = L.dev_f32(dirs, dev).reshape(n, 3)
+                L.check(lib.nrf_mlp_forward_train(h, mode, L.ptr(pts), L.ptr(dirs_d), n, L.ptr(rgb), L.ptr(den), ctx, self.nbytes, st))
+                L.check(lib.nrf_composite(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(self.pred), None, None, st))
+            else:
+                L.check(lib.nrf_mlp_forward_train_v1(h, mode, L.ptr(pts), n, L.ptr(o4), ctx, self.nbytes, st))
+                L.check(lib.nrf_composite(L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, self.white,
+                                          L.ptr(self.pred), None, None, st))
+            # loss = w * mean((pred - target)^2) over R*3 elements; d loss / d pred = 2 w (pred - target) / (3 R)
+            torch.sub(self.pred, tgt, out=self.g_pred)
+            loss = self.g_pred.square().mean() * self.rgb_weight
+            self.g_pred.mul_(2.0 * self.rgb_weight / (3 * R))
+            if v2:
+                L.check(lib.nrf_composite_backward(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(self.g_pred), None, None,
+                                                   L.ptr(g_rgb), 3, L.ptr(g_den), 1, st))
+            else:
+                L.check(lib.nrf_composite_backward(L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, self.white,
+                                                   L.ptr(self.g_pred), None, None, L.ptr(d4), 4, C.c_void_p(d4.data_ptr() + 12), 4, st))
+            self.grad.zero_()
+            if v2:
+                L.check(lib.nrf_mlp_backward(h, mode, L.ptr(rgb), L.ptr(den), L.ptr(g_rgb), L.ptr(g_den), n, ctx, self.nbytes, L.ptr(self.grad), st))
+            else:
+                L.check(lib.nrf_mlp_backward_v1(h, mode, L.ptr(o4), L.ptr(d4), n, ctx, self.nbytes, L.ptr(self.grad), st))
+            opt = self.opt
+            fp, flat = opt._buffers()
+            opt.step_count += 1
+            L.check(lib.nrf_adam_step(L.ptr(flat), L.ptr(self.grad), L.ptr(opt.exp_avg), L.ptr(opt.exp_avg_sq), flat.numel(), opt.lr, opt.betas[0],
+                                      opt.betas[1], opt.eps, opt.weight_decay, opt.step_count, st))
+        m._gen += 1
+        return loss

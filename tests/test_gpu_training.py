@@ -548,3 +548,45 @@ def test_v2_train_step_as_train_py_runs_it(N):
         opt.step()
         gpu_losses.append(loss.item())
     assert np.allclose(cpu_losses, gpu_losses, rtol=2e-4, atol=1e-6), (cpu_losses, gpu_losses)
+
+
+# ---------------------------------------------------------------------------------------------
+# FusedStep: the same step without autograd in between
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("net,mode", [("v1", "f32"), ("v1", "bf16"), ("v2", "f32"), ("v2", "bf16")])
+def test_fused_step_equals_autograd_route(N, net, mode):
+    from nerf_few_shot_limitations_amd.training import Adam, FusedStep
+    R, S, steps = 160, 32, 4
+    z = torch.sort(torch.from_numpy(O.uniform01(101, R * S).reshape(R, S) * 4 + 2).float(), dim=-1).values.cuda()
+    rd = torch.from_numpy(O.uniform01(102, R * 3).reshape(R, 3) - 0.5).float().cuda()
+    tgt = torch.from_numpy(O.uniform01(103, R * 3).reshape(R, 3)).float().cuda()
+    pos = torch.from_numpy(O.uniform01(104, R * S * 3).reshape(R * S, 3) * 4 - 2).float()
+    dirs = rd[:, None, :].expand(R, S, 3).reshape(-1, 3).contiguous()
+    if net == "v1":
+        a, _ = make_model(N, mode, scene="solid")
+        b, _ = make_model(N, mode, scene="solid")
+        pts = O.positional_encoding(pos, 10).cuda()
+    else:
+        a, _ = make_v2(N, mode, scene="solid")
+        b, _ = make_v2(N, mode, scene="solid")
+        pts = pos.cuda()
+    opt = Adam(a, lr=5e-4, weight_decay=1e-6)
+    vr = N.VolumeRenderer()
+    ref_losses = []
+    for _ in range(steps):
+        opt.zero_grad()
+        if net == "v1":
+            pred = N.volume_render_radiance(a(pts).view(R, 1, S, 4), z.view(R, 1, S), rd.view(R, 1, 3)).view(R, 3)
+        else:
+            c, sg = a(pts, dirs, None)
+            pred = vr(c.view(R, S, 3), sg.view(R, S, 1), z, rd)[0]
+        loss = torch.nn.functional.mse_loss(pred, tgt)
+        loss.backward()
+        opt.step()
+        ref_losses.append(loss.item())
+    step = FusedStep(b, lr=5e-4, weight_decay=1e-6)
+    got = [step(pts, z, rd, tgt, dirs=dirs if net == "v2" else None).item() for _ in range(steps)]
+    # same kernels on both routes; only the fp32 atomics of the weight gradients are order dependent, and Adam's first
+    # steps turn gradient noise around 0 into +-lr -- the 16-bit modes then see different operand roundings
+    assert np.allclose(ref_losses, got, rtol=1e-5 if mode == "f32" else 2e-3, atol=1e-7), (ref_losses, got)
+    assert got[-1] < got[0]

@@ -187,6 +187,16 @@ int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear
                    uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes,
                    float* bias_out, int64_t bias_cap, int64_t* n_bias);
 
+/* Host-only, like nrf_debug_pack, for the training path: the transposed (backward-chain) fragment stream, and the
+ * saved-tensor / weight-gradient plan serialised as int32:
+ *   n_slots, slot_tiles[n_slots], n_jobs, then per job: x_slot, dz_slot, KT, MT, x_first,
+ *   row_w[32*MT], row_b[32*MT] (flat-parameter offsets of the weight row / of the bias, -1 = none), col[32*KT].
+ * Used by the CPU tests to replay the backward pass through a numpy model of the MFMA lane maps. */
+int nrf_debug_pack_backward(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int mma_mode,
+                            uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes);
+int nrf_debug_train_plan(const nrf_arch* arch, const nrf_linear* linears, int n_linear,
+                         int32_t* out, int64_t cap, int64_t* n_ints);
+
 /* ---- misc ------------------------------------------------------------------ */
 const char* nrf_last_error(void);
 int nrf_abi_version(void);

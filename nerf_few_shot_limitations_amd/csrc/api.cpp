@@ -600,6 +600,50 @@ int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear
     return NRF_OK;
 }
 
+int nrf_debug_pack_backward(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int mma_mode, uint8_t* stream_out, int64_t stream_cap,
+                            int64_t* stream_bytes) {
+    if (!arch || !linears || n_linear <= 0) return fail(NRF_EINVAL, "nrf_debug_pack_backward: null argument");
+    if (mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "unknown mma_mode");
+    std::string err;
+    std::vector<nrf::HostLinear> lin;
+    nrf::NetPlan plan, bplan;
+    if (!copy_linears(linears, n_linear, lin, err) || !nrf::make_plan(*arch, lin, plan, err)) return fail(NRF_EINVAL, err);
+    if (!nrf::make_backward_plan(*arch, lin, bplan, err)) return fail(NRF_EUNSUPPORTED, err);
+    const nrf::PackedStream ps = nrf::pack_stream(bplan, lin, mma_mode);
+    if (stream_bytes) *stream_bytes = (int64_t)ps.bytes.size();
+    if (stream_out) {
+        if (stream_cap < (int64_t)ps.bytes.size()) return fail(NRF_EINVAL, "stream_out too small");
+        std::memcpy(stream_out, ps.bytes.data(), ps.bytes.size());
+    }
+    return NRF_OK;
+}
+
+int nrf_debug_train_plan(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int32_t* out, int64_t cap, int64_t* n_ints) {
+    if (!arch || !linears || n_linear <= 0) return fail(NRF_EINVAL, "nrf_debug_train_plan: null argument");
+    std::string err;
+    std::vector<nrf::HostLinear> lin;
+    nrf::NetPlan plan;
+    nrf::TrainPlan tp;
+    if (!copy_linears(linears, n_linear, lin, err) || !nrf::make_plan(*arch, lin, plan, err)) return fail(NRF_EINVAL, err);
+    if (!nrf::make_train_plan(*arch, plan, nrf::param_layout(lin), tp, err)) return fail(NRF_EUNSUPPORTED, err);
+    std::vector<int32_t> v;
+    v.push_back((int32_t)tp.slot_tiles.size());
+    v.insert(v.end(), tp.slot_tiles.begin(), tp.slot_tiles.end());
+    v.push_back((int32_t)tp.jobs.size());
+    for (const auto& J : tp.jobs) {
+        v.push_back(J.x_slot); v.push_back(J.dz_slot); v.push_back(J.KT); v.push_back(J.MT); v.push_back(J.x_first);
+        v.insert(v.end(), J.row_w.begin(), J.row_w.end());
+        v.insert(v.end(), J.row_b.begin(), J.row_b.end());
+        v.insert(v.end(), J.col.begin(), J.col.end());
+    }
+    if (n_ints) *n_ints = (int64_t)v.size();
+    if (out) {
+        if (cap < (int64_t)v.size()) return fail(NRF_EINVAL, "out too small");
+        std::memcpy(out, v.data(), v.size() * sizeof(int32_t));
+    }
+    return NRF_OK;
+}
+
 int nrf_project_fetch(const nrf_dino* dino, const float* points, int64_t n, float* feats, float* xy, void* stream) {
     if (n < 0) return fail(NRF_EINVAL, "n < 0");
     if (n == 0) return NRF_OK;

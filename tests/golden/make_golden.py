@@ -247,5 +247,70 @@ def main():
     save("end_to_end", **e2e)
 
 
+def select_rays(margin_per_sample, R, S, need):
+    """Indices of the first `need` rays all of whose samples keep every ReLU pre-activation away from 0 (oracle.relu_margin):
+    for the others the ReLU mask -- hence the gradient -- is decided by summation order, in the reference as anywhere."""
+    ok = (margin_per_sample.reshape(R, S) > 1e-4).all(dim=1).nonzero().flatten()
+    assert ok.numel() >= need, (ok.numel(), need)
+    return ok[:need]
+
+
+def thin(t):
+    """Large gradient matrices are stored as every 4th row (the fixture stays small; tests slice the same way)."""
+    return t[::4] if t.ndim == 2 and t.numel() > 20000 else t
+
+
+def training():
+    """One loss.backward() of the reference's own modules (src/training/train_minimal.py:97-122 for V1; train.py:229-287
+    with nerf_mlp.NeRFLoss for V2): inputs, loss and every parameter gradient."""
+    out = {}
+    S, cand, R = 8, 400, 96
+    c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
+    ro, rd = ref_get_rays_flat(20, 20, O.focal_for(20), c2w)
+    ro, rd = ro.reshape(-1, 3)[:cand], rd.reshape(-1, 3)[:cand]
+    tr = torch.from_numpy(O.uniform01(301, cand * S).reshape(cand, S)).float()
+    with _patched_rand(tr):
+        pts, z = ref_sample_flat(ro, rd, 2.0, 6.0, S, perturb=True)
+    dirs = rd.unsqueeze(1).expand(-1, S, -1)
+    tgt_all = torch.from_numpy(O.uniform01(302, cand * 3).reshape(cand, 3)).float()
+    # ---- V1: NeRFMLP(pos_dim=63, n_layers=3) -> volume_render_radiance -> mse
+    p1 = O.make_weights("v1", 0, "solid", n_layers=3)
+    keep = select_rays(O.relu_margin(p1, "v1", O.positional_encoding(pts.reshape(-1, 3), 10)), cand, S, R)
+    m1 = RefNeRFMLP(pos_dim=63, hidden_dim=256, n_layers=3)
+    m1.load_state_dict(p1)
+    with torch.enable_grad():
+        x = RefPE(10)(pts[keep].reshape(-1, 3))
+        pred = ref_vrr(m1(x).view(R, 1, S, 4), z[keep].view(R, 1, S), rd[keep].view(R, 1, 3)).view(R, 3)
+        loss = torch.nn.functional.mse_loss(pred, tgt_all[keep])
+        loss.backward()
+    out.update(v1_pts=npf(pts[keep]), v1_z=npf(z[keep]), v1_rays_d=npf(rd[keep]), v1_target=npf(tgt_all[keep]), v1_pred=npf(pred),
+               v1_loss=np.float32(loss.item()))
+    for k, q in m1.named_parameters():
+        out["v1_grad_" + k] = npf(thin(q.grad))
+    # ---- V2: DensityMLP(63,256,3) + ColorMLP(256,27,128) -> VolumeRenderer -> NeRFLoss (rgb + 0.01 * mean(weights^2))
+    p2 = O.make_weights("v2", 1, "solid", n_layers=3)
+    keep = select_rays(O.relu_margin(p2, "v2", pts.reshape(-1, 3), dirs.reshape(-1, 3)), cand, S, R)
+    dm, cm = ref_mlp.DensityMLP(63, 256, 3), ref_mlp.ColorMLP(256, 27, 128)
+    dm.load_state_dict({k[len("density_mlp."):]: v for k, v in p2.items() if k.startswith("density_mlp.")})
+    cm.load_state_dict({k[len("color_mlp."):]: v for k, v in p2.items() if k.startswith("color_mlp.")})
+    vr, crit = ref_mlp.VolumeRenderer(), ref_mlp.NeRFLoss()
+    pe10, pe4 = ref_mlp.PositionalEncoding(10), ref_mlp.PositionalEncoding(4)
+    with torch.enable_grad():
+        dn, ft = dm(pe10(pts[keep].reshape(-1, 3)))
+        col = cm(ft, pe4(dirs[keep].reshape(-1, 3)))
+        rgb_map, depth_map, w = vr(col.reshape(R, S, 3), dn.reshape(R, S, 1), z[keep], rd[keep])
+        losses = crit({"rgb": rgb_map, "depth": depth_map, "weights": w}, {"rgb": tgt_all[keep]})
+        losses["total"].backward()
+    out.update(v2_pts=npf(pts[keep]), v2_dirs=npf(dirs[keep]), v2_z=npf(z[keep]), v2_rays_d=npf(rd[keep]), v2_target=npf(tgt_all[keep]),
+               v2_pred=npf(rgb_map), v2_loss=np.float32(losses["total"].item()))
+    for k, q in dm.named_parameters():
+        out["v2_grad_density_mlp." + k] = npf(thin(q.grad))
+    for k, q in cm.named_parameters():
+        out["v2_grad_color_mlp." + k] = npf(thin(q.grad))
+    save("train_grads", **out)
+
+
 if __name__ == "__main__":
-    main()
+    if "--training-only" not in sys.argv:
+        main()
+    training()

@@ -551,6 +551,44 @@ def test_v2_train_step_as_train_py_runs_it(N):
 
 
 # ---------------------------------------------------------------------------------------------
+# golden: loss.backward() of the reference's own modules (tests/golden/make_golden.py: training())
+# ---------------------------------------------------------------------------------------------
+def thin(t):
+    return t[::4] if t.ndim == 2 and t.numel() > 20000 else t
+
+
+def test_v1_backward_matches_reference_golden(N, golden):
+    g = golden("train_grads")
+    R, S = g["v1_z"].shape
+    model, _ = make_model(N, "f32", scene="solid", n_layers=3)
+    x = O.positional_encoding(torch.from_numpy(g["v1_pts"]).reshape(-1, 3), 10).cuda()
+    pred = N.volume_render_radiance(model(x).view(R, 1, S, 4), torch.from_numpy(g["v1_z"]).view(R, 1, S).cuda(),
+                                    torch.from_numpy(g["v1_rays_d"]).view(R, 1, 3).cuda()).view(R, 3)
+    loss = torch.nn.functional.mse_loss(pred, torch.from_numpy(g["v1_target"]).cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g["v1_loss"])) < 1e-5 * float(g["v1_loss"]) + 1e-7
+    assert (pred.detach().cpu().numpy() - g["v1_pred"]).max() < 1e-4
+    for name, q in model.named_parameters():
+        ref = g["v1_grad_" + name]
+        assert np.abs(thin(q.grad).cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), name
+
+
+def test_v2_backward_matches_reference_golden(N, golden):
+    g = golden("train_grads")
+    R, S = g["v2_z"].shape
+    model, _ = make_v2(N, "f32", scene="solid", n_layers=3)
+    rgb, den = model(torch.from_numpy(g["v2_pts"]).reshape(-1, 3).cuda(), torch.from_numpy(g["v2_dirs"]).reshape(-1, 3).cuda(), None)
+    rgb_map, depth_map, w = N.VolumeRenderer()(rgb.reshape(R, S, 3), den.reshape(R, S, 1), torch.from_numpy(g["v2_z"]).cuda(),
+                                              torch.from_numpy(g["v2_rays_d"]).cuda())
+    loss = torch.nn.functional.mse_loss(rgb_map, torch.from_numpy(g["v2_target"]).cuda()) + 0.01 * torch.mean(w ** 2)   # nerf_mlp.py:236-252
+    loss.backward()
+    assert abs(loss.item() - float(g["v2_loss"])) < 1e-5 * float(g["v2_loss"]) + 1e-7
+    for name, q in model.named_parameters():
+        ref = g["v2_grad_" + name]
+        assert np.abs(thin(q.grad).cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), name
+
+
+# ---------------------------------------------------------------------------------------------
 # FusedStep: the same step without autograd in between
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("net,mode", [("v1", "f32"), ("v1", "bf16"), ("v2", "f32"), ("v2", "bf16")])

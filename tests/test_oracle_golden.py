@@ -211,3 +211,60 @@ def test_uniform01_is_stable():
     # frozen values: the GPU box must regenerate the same inputs
     assert np.array_equal(u, O.uniform01(1234, 8)[:5])
     assert [int(x * 2 ** 24) for x in O.uniform01(0, 3)] == [int(x * 2 ** 24) for x in O.uniform01(0, 3)]
+
+
+# ---------------------------------------------------------------------------------------------
+# training path: the oracle's autograd against loss.backward() of the reference's own modules
+# ---------------------------------------------------------------------------------------------
+def thin(t):
+    return t[::4] if t.ndim == 2 and t.numel() > 20000 else t
+
+
+def test_training_gradients_v1_match_reference_backward(golden):
+    g = golden("train_grads")
+    R, S = g["v1_z"].shape
+    p = O.make_weights("v1", 0, "solid", n_layers=3)
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    x = O.positional_encoding(torch.from_numpy(g["v1_pts"]).reshape(-1, 3), 10)
+    pred = O.volume_render_radiance(O.mlp_v1(pp, x).reshape(R, 1, S, 4), torch.from_numpy(g["v1_z"]).reshape(R, 1, S),
+                                    torch.from_numpy(g["v1_rays_d"]).reshape(R, 1, 3)).reshape(R, 3)
+    loss = torch.nn.functional.mse_loss(pred, torch.from_numpy(g["v1_target"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["v1_loss"])) < 1e-6
+    assert np.abs(pred.detach().numpy() - g["v1_pred"]).max() < 1e-6
+    n = 0
+    for k, v in pp.items():
+        ref = g["v1_grad_" + k]
+        assert np.abs(thin(v.grad).numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), k
+        n += 1
+    assert n == 10
+
+
+def test_training_gradients_v2_match_reference_backward(golden):
+    """train.py's model + VolumeRenderer + nerf_mlp.NeRFLoss (rgb + 0.01 * mean(weights^2)): nerf_mlp.py:217-256."""
+    g = golden("train_grads")
+    R, S = g["v2_z"].shape
+    p = O.make_weights("v2", 1, "solid", n_layers=3)
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    rgb, den = O.mlp_v2(pp, torch.from_numpy(g["v2_pts"]).reshape(-1, 3), torch.from_numpy(g["v2_dirs"]).reshape(-1, 3))
+    rgb_map, _, w = O.volume_render(rgb.reshape(R, S, 3), den.reshape(R, S, 1), torch.from_numpy(g["v2_z"]), torch.from_numpy(g["v2_rays_d"]))
+    loss = torch.nn.functional.mse_loss(rgb_map, torch.from_numpy(g["v2_target"])) + 0.01 * torch.mean(w ** 2)
+    loss.backward()
+    assert abs(loss.item() - float(g["v2_loss"])) < 1e-6
+    for k, v in pp.items():
+        ref = g["v2_grad_" + k]
+        assert np.abs(thin(v.grad).numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), k
+
+
+def test_emulated_training_arithmetic_is_autograd_in_fp32():
+    """The rounding-aware restatement used to check the 16-bit kernels is, without rounding, exactly autograd."""
+    p = O.make_weights("v1", 0, "solid")
+    x = torch.from_numpy(O.uniform01(3, 200 * 63).reshape(200, 63) * 2 - 1).float()
+    gg = torch.from_numpy(O.uniform01(4, 800).reshape(200, 4) - 0.5).float()
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    out = O.mlp_v1(pp, x)
+    (out * gg).sum().backward()
+    out2, grads, _, _ = O.mlp_v1_train_emulated(p, x, gg, "f32")
+    assert torch.equal(out.detach(), out2)
+    for k, v in grads.items():
+        assert (pp[k].grad - v).abs().max() <= 2e-6 * pp[k].grad.abs().max(), k

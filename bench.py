@@ -34,6 +34,41 @@ sys.path.insert(0, ROOT)
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
 
 
+def training_line(N, args, dev):
+    """SURVEY.md section 8 row f1, reported next to the render metric (not part of `value`): one optimisation step of the
+    reference's loop (train.py:280-288 / train_minimal.py:102-123: render a ray batch, mse on rgb, backward, Adam) at the
+    reference's own batch (baseline.yaml:32-34: 2048 rays x 32 samples), random-init weights, through training.FusedStep."""
+    from nerf_few_shot_limitations_amd.training import FusedStep
+    R, S = 2048, 32
+    torch.manual_seed(0)
+    if args.net == "v2":
+        m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=args.mode).to(dev).train()
+        pts = torch.rand(R * S, 3, device=dev) * 4 - 2
+    else:
+        m = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=args.mode).to(dev).train()
+        pts = torch.rand(R * S, 63, device=dev) * 2 - 1
+    dirs = torch.rand(R * S, 3, device=dev) * 2 - 1
+    z = torch.sort(torch.rand(R, S, device=dev) * 4 + 2, dim=-1).values.contiguous()
+    d = torch.rand(R, 3, device=dev) - 0.5
+    tgt = torch.rand(R, 3, device=dev)
+    step = FusedStep(m, lr=5e-4, weight_decay=1e-6)
+    kw = dict(dirs=dirs) if args.net == "v2" else {}
+    first = None
+    for _ in range(3):
+        loss = step(pts, z, d, tgt, **kw)
+        first = loss.item() if first is None else first
+    torch.cuda.synchronize()
+    k = 50
+    t0 = time.perf_counter()
+    for _ in range(k):
+        loss = step(pts, z, d, tgt, **kw)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    return {"metric": "M ray-samples/s per optimisation step (forward + backward + Adam)", "value": round(R * S / dt / 1e6, 2),
+            "ms_per_step": round(dt * 1e3, 4), "rays": R, "samples_per_ray": S, "net": args.net, "dtype": args.mode,
+            "loss_first": round(first, 6), "loss_last": round(loss.item(), 6), "bound": "hbm (saved activations, profiles/r01_train_pmc_summary.json)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -47,6 +82,7 @@ def main():
     ap.add_argument("--scene", default="solid", choices=["fog", "solid", "smooth"])
     ap.add_argument("--ert", type=float, default=0.0)
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per pixel tile; 0 = largest <= 16 that deals the tiles evenly")
+    ap.add_argument("--no-train", action="store_true", help="skip the optimisation-step timing appended as 'training' (N=1 only)")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
     args = ap.parse_args()
 
@@ -219,6 +255,8 @@ def main():
             "f32_max_abs_rgb": float((rgb32.cpu() - ref["rgb"]).abs().max()),
             "f32_max_abs_depth": float((depth32.cpu() - ref["depth"]).abs().max()),
         }
+    if rank == 0 and world == 1 and args.net in ("v1", "v2") and not args.no_train:
+        out["training"] = training_line(N, args, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

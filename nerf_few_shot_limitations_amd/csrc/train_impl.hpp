@@ -242,8 +242,8 @@ struct GradKArgs {
     float* grad;                // flat gradient vector, accumulated into
     const int32_t* maps;
     GradJob jobs[kMaxJobs];
+    int first_block[kMaxJobs + 1];   // job j owns workgroups [first_block[j], first_block[j+1]): its slabs of the sample axis
     int n_jobs;
-    int splits;                 // workgroups per job along the sample axis
     int64_t n_tiles32;          // 32-sample tiles
 };
 
@@ -263,7 +263,9 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
     constexpr int kStageBytes = ST * 16 * TB;
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int job = blockIdx.x / P.splits, split = blockIdx.x % P.splits;
+    int job = 0;
+    while (job + 1 < P.n_jobs && (int)blockIdx.x >= P.first_block[job + 1]) ++job;
+    const int split = blockIdx.x - P.first_block[job], splits = P.first_block[job + 1] - P.first_block[job];
     const GradJob J = P.jobs[job];
     const int row0 = (wave & 3) * RT, col0 = (wave >> 2) * CT;
     const bool has_z = wave < J.MT, has_x = wave < J.KT;            // transposition duty: dZ tile `wave`, X tile `wave`
@@ -277,7 +279,7 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
 #pragma unroll
         for (int j = 0; j < CT; ++j) acc[i][j] = f32x16{};
 
-    const int64_t per = (P.n_tiles32 + P.splits - 1) / P.splits;
+    const int64_t per = (P.n_tiles32 + splits - 1) / splits;
     const int64_t t0 = split * per, t1 = (t0 + per < P.n_tiles32) ? t0 + per : P.n_tiles32;
     const char* xb = P.ctx + J.x_off + lane * 16;
     const char* zb = P.ctx + J.dz_off + lane * 16;

@@ -1,4 +1,6 @@
 // train_v1.hip -- host launchers of the training path (V1, pos_freq 10): train_impl.hpp
+#include <algorithm>
+
 #include "train_impl.hpp"
 
 namespace nrf {
@@ -95,16 +97,27 @@ int run_weight_grad(const DeviceNet& net, const TrainDev& t, const TrainKArgs& k
         g.jobs[j].x_first = t.job_x_first[j];
         g.jobs[j].map_off = j * kMapStride;
     }
-    // one workgroup per CU (128 KiB of LDS).  Every workgroup ends with 64 Ki atomic adds, so small batches get one round
-    // of workgroups and large ones two (measured: 65 Ki samples 0.29 vs 0.34 ms, 1 Mi samples 3.47 vs 3.38 ms)
+    // One workgroup per CU (128 KiB of LDS), and every workgroup ends with up to 64 Ki atomic adds: small batches get ONE
+    // round of workgroups, large ones two.  The workgroups of a round are dealt to the jobs in proportion to the bytes a
+    // job reads per sample (KT + MT saved tiles), so that all of them finish together and the grid never exceeds the
+    // round (a 257th workgroup would run alone after the other 256).
     const int rounds = g.n_tiles32 >= 8192 ? 2 : 1;
     constexpr int min_stages = 4;
-    int64_t splits = (rounds * (int64_t)net.cu_count + t.n_jobs - 1) / t.n_jobs;
-    const int64_t max_splits = (g.n_tiles32 + min_stages * ST - 1) / (min_stages * ST);
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    g.splits = (int)splits;
-    const unsigned grid = (unsigned)(t.n_jobs * splits);
+    const int64_t max_splits = std::max<int64_t>(1, (g.n_tiles32 + min_stages * ST - 1) / (min_stages * ST));
+    const int budget = rounds * net.cu_count;
+    static const int cost_floor = [] { const char* e = getenv("NRF_WGRAD_COST_FLOOR"); return e ? atoi(e) : 10; }();
+    auto cost = [&](int j) { return std::max(t.job_KT[j] + t.job_MT[j], cost_floor); };   // a stage costs a load latency + a barrier however few tiles it moves
+    int cost_sum = 0;
+    for (int j = 0; j < t.n_jobs; ++j) cost_sum += cost(j);
+    int next = 0;
+    for (int j = 0; j < t.n_jobs; ++j) {
+        int64_t sp = (int64_t)budget * cost(j) / cost_sum;      // floor: the sum stays within the budget
+        sp = std::max<int64_t>(1, std::min<int64_t>(sp, max_splits));
+        g.first_block[j] = next;
+        next += (int)sp;
+    }
+    g.first_block[t.n_jobs] = next;
+    const unsigned grid = (unsigned)next;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), kLds, s, g);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("weight gradient launch: ") + hipGetErrorString(e); return NRF_EHIP; }

@@ -63,6 +63,33 @@ class FlatParams:
         return [vec[off:off + p.numel()].view(p.shape) for p, off in zip(self.params(), self.offsets)]
 
 
+def _grad_target(module):
+    """Where a backward should accumulate: (flat vector, attach).  The gradients live in ONE persistent flat vector whose
+    per-parameter views are the parameters' .grad, so the kernels add into it directly and autograd's per-parameter
+    AccumulateGrad (20+ tensors cloned and added per step) is bypassed.  Cases:
+      * every .grad is None (after zero_grad(set_to_none=True)): zero the vector, attach the views;
+      * every .grad already is our view: accumulate (two backward calls before a step add up, as in torch);
+      * anything else (someone else produced some .grad): return None -- the caller falls back to handing autograd
+        ordinary gradient tensors."""
+    fp = module.flat_params()
+    ps = fp.params()
+    flat = fp.flat
+    fg = getattr(module, "_flat_grad", None)
+    if fg is None or fg.shape != flat.shape or fg.device != flat.device:
+        fg = module._flat_grad = torch.zeros_like(flat)
+        module._flat_grad_views = fp.views(fg)
+    grads = [p.grad for p in ps]
+    if all(g is None for g in grads):
+        fg.zero_()
+        for p, v in zip(ps, module._flat_grad_views):
+            p.grad = v
+        return fg
+    base = fg.data_ptr()
+    if all(g is not None and g.data_ptr() == base + 4 * off and g.shape == p.shape for g, p, off in zip(grads, ps, fp.offsets)):
+        return fg
+    return None
+
+
 def _train_handle(module, dev):
     """nrf_model* with forward AND backward streams matching the current parameter values."""
     module.flat_params().ensure()
@@ -107,11 +134,14 @@ class _MLPV1Fn(torch.autograd.Function):
         dev = out.device
         g = g_out.to(torch.float32).contiguous()
         fp = module.flat_params()
-        grad = torch.zeros_like(fp.flat)
+        direct = _grad_target(module)
+        grad = direct if direct is not None else torch.zeros_like(fp.flat)
         with torch.cuda.device(dev):
             L.check(L.lib().nrf_mlp_backward_v1(module._handle, ctx.mode, L.ptr(out), L.ptr(g), ctx.n, C.c_void_p(ctx.buf.data_ptr()), ctx.nbytes,
                                                 L.ptr(grad), L.stream_ptr()))
         ctx.buf = None
+        if direct is not None:
+            return (None, None) + (None,) * len(fp.offsets)       # already accumulated into the parameters' .grad
         return (None, None, *fp.views(grad))
 
 
@@ -148,11 +178,14 @@ class _MLPV2Fn(torch.autograd.Function):
         g_rgb = g_rgb.to(torch.float32).contiguous()
         g_dens = g_dens.to(torch.float32).contiguous()
         fp = module.flat_params()
-        grad = torch.zeros_like(fp.flat)
+        direct = _grad_target(module)
+        grad = direct if direct is not None else torch.zeros_like(fp.flat)
         with torch.cuda.device(dev):
             L.check(L.lib().nrf_mlp_backward(module._handle, ctx.mode, L.ptr(rgb), L.ptr(dens), L.ptr(g_rgb), L.ptr(g_dens), ctx.n,
                                              C.c_void_p(ctx.buf.data_ptr()), ctx.nbytes, L.ptr(grad), L.stream_ptr()))
         ctx.buf = None
+        if direct is not None:
+            return (None, None, None) + (None,) * len(fp.offsets)
         return (None, None, None, *fp.views(grad))
 
 
@@ -247,6 +280,8 @@ class Adam:
         flat gradient in exactly this layout and autograd keeps them when nothing else accumulated)."""
         g0 = ps[0].grad
         base = getattr(g0, "_base", None) if g0 is not None else None
+        if base is not None and base.dim() != 1:
+            base = None
         if base is None or base.shape != flat.shape or base.dtype != torch.float32 or base.device != flat.device or not base.is_contiguous():
             return None
         b = base.data_ptr()

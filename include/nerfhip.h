@@ -190,7 +190,8 @@ int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear
 /* Host-only, like nrf_debug_pack, for the training path: the transposed (backward-chain) fragment stream, and the
  * saved-tensor / weight-gradient plan serialised as int32:
  *   n_slots, slot_tiles[n_slots], n_jobs, then per job: x_slot, dz_slot, KT, MT, x_first,
- *   row_w[32*MT], row_b[32*MT] (flat-parameter offsets of the weight row / of the bias, -1 = none), col[32*KT].
+ *   row_w[32*MT], row_b[32*MT] (flat-parameter offsets of the weight row / of the bias, -1 = none), col[32*KT];
+ *   finally n_mask_planes (ReLU-mask bit planes of 1 KiB per 32 samples appended to the context).
  * Used by the CPU tests to replay the backward pass through a numpy model of the MFMA lane maps. */
 int nrf_debug_pack_backward(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int mma_mode,
                             uint8_t* stream_out, int64_t stream_cap, int64_t* stream_bytes);

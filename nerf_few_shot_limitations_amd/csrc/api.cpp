@@ -168,7 +168,7 @@ int ensure_train(nrf_model* m) {
     std::string err;
     if (!nrf::make_backward_plan(m->arch, m->lin, m->bplan, err) || !nrf::make_train_plan(m->arch, m->plan, m->layout, m->tplan, err))
         return fail(NRF_EUNSUPPORTED, err);
-    if ((int)m->tplan.slot_tiles.size() > nrf::kMaxSlots || (int)m->tplan.jobs.size() > nrf::kMaxJobs)
+    if ((int)m->tplan.slot_tiles.size() > nrf::kMaxSlots || (int)m->tplan.jobs.size() > nrf::kMaxJobs || m->tplan.n_mask_slots > nrf::kMaxMaskSlots)
         return fail(NRF_EUNSUPPORTED, "network too deep for the training path");
     for (int mode = 0; mode < 3; ++mode) {
         const nrf::PackedStream ps = nrf::pack_stream(m->bplan, m->lin, mode);
@@ -200,6 +200,7 @@ int ensure_train(nrf_model* m) {
     m->train.n_jobs = nj;
     m->train.n_slots = (int)m->tplan.slot_tiles.size();
     for (int i = 0; i < m->train.n_slots; ++i) m->train.slot_tiles[i] = m->tplan.slot_tiles[i];
+    m->train.n_mask_slots = m->tplan.n_mask_slots;
     m->train.n_params = m->layout.total;
     m->train_ready = true;
     return NRF_OK;
@@ -636,6 +637,7 @@ int nrf_debug_train_plan(const nrf_arch* arch, const nrf_linear* linears, int n_
         v.insert(v.end(), J.row_b.begin(), J.row_b.end());
         v.insert(v.end(), J.col.begin(), J.col.end());
     }
+    v.push_back(tp.n_mask_slots);
     if (n_ints) *n_ints = (int64_t)v.size();
     if (out) {
         if (cap < (int64_t)v.size()) return fail(NRF_EINVAL, "out too small");

@@ -74,6 +74,7 @@ int launch_forward(const DeviceNet& net, int mma_mode, const float* pos, const f
 // ---- training path (train_v1.hip) -------------------------------------------------
 constexpr int kMaxSlots = 40;
 constexpr int kMaxJobs = 20;
+constexpr int kMaxMaskSlots = 20;
 constexpr int kMapStride = 3 * 320;      // per weight-gradient job: row_w[320] | row_b[320] | col[320]
 
 struct TrainDev {
@@ -82,6 +83,7 @@ struct TrainDev {
     const int32_t* maps;        // device, n_jobs * kMapStride
     int n_slots;
     int slot_tiles[kMaxSlots];  // feature tiles per saved-tensor slot
+    int n_mask_slots;           // ReLU-mask bit planes (one per masked layer)
     int n_jobs;
     int job_x_slot[kMaxJobs], job_dz_slot[kMaxJobs], job_KT[kMaxJobs], job_MT[kMaxJobs], job_x_first[kMaxJobs];
     int64_t n_params;

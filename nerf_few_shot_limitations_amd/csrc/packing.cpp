@@ -368,12 +368,14 @@ bool make_train_plan(const nrf_arch& a, const NetPlan& fwd, const ParamLayout& l
         tp.slot_tiles.assign(2 * n + 2, 8);
         tp.slot_tiles[0] = fwd.layers[0].KT;
         tp.slot_tiles[2 * n + 1] = 1;
+        tp.n_mask_slots = n;                                       // plane l: ReLU of layers.{l}
         for (int l = 0; l <= n; ++l) add_job(fwd.layers[l], l, l < n ? n + 1 + l : 2 * n + 1, 0, fwd.layers[l].KT, true);
         return true;
     }
     tp.slot_tiles.assign(2 * n + 9, 8);
     tp.slot_tiles[0] = fwd.layers[0].KT;
     tp.slot_tiles[n + 1] = 9; tp.slot_tiles[n + 2] = 4; tp.slot_tiles[n + 3] = 2;
+    tp.n_mask_slots = n + 2;                                       // trunk planes 0..n-1, colour layer 0 (n), colour layer 2 (n+1)
     tp.slot_tiles[2 * n + 4] = 1; tp.slot_tiles[2 * n + 6] = 4; tp.slot_tiles[2 * n + 7] = 2; tp.slot_tiles[2 * n + 8] = 1;
     for (int l = 0; l < n; ++l) add_job(fwd.layers[l], l, n + 4 + l, 0, fwd.layers[l].KT, true);
     add_job(fwd.layers[n], n, 2 * n + 4, 0, 8, true);              // density_head

@@ -1,5 +1,5 @@
 // train_core.hpp -- device helpers of the training path: the activation store,
-// the ReLU-mask epilogue of the backward chain and the MFMA transpose the weight-gradient kernel is built on.
+// the ReLU-mask bits of the backward chain and the MFMA transpose the weight-gradient kernel is built on.
 //
 // Saved tensors ("context").  Every operand tile of the forward chain (32 features x 32 samples of one wave,
 // mlp_core.hpp) is written to HBM exactly as the lanes hold it: sizeof(Act)/16 vectors of 64 lanes x 16 B, each
@@ -17,8 +17,6 @@
 #include "mlp_core.hpp"
 
 namespace nrf {
-
-typedef __attribute__((ext_vector_type(2))) unsigned short u16x2;
 
 template <class Mode> struct ActIO;
 
@@ -64,48 +62,46 @@ struct ActIO<ModeF32> {
 template <class Mode>
 constexpr __host__ __device__ int tile_bytes() { return ActIO<Mode>::kVecs * kFragBytes; }
 
-// dZ = dH where the forward activation was positive, else 0 (ReLU'), converted to the operand type.
-// x holds relu(.) >= 0 in the operand type: "positive" == "non-zero bit pattern".
-// 0xffff in every 16-bit half of x that is non-zero (x = two non-negative 16-bit floats): min(x, 1) is 0 / 1 per half,
-// 0 - that is 0 / 0xffff.  Inline asm: the packed-integer idiom written with clang's vector builtins was folded into
-// ONE mask for all four dwords of a fragment (seen in the ISA and in the parity test).
-__device__ __forceinline__ int nonzero_halves(int x) {
-    int m;
-    const int ones = 0x00010001;
-    asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(x), "v"(ones));
-    asm("v_pk_sub_u16 %0, 0, %1" : "=v"(m) : "v"(m));
-    return m;
+// ReLU' travels from the forward to the backward chain as BITS, not as the activation tiles themselves (which the
+// backward chain would otherwise re-read: 2 KiB per tile against 128 B): per lane and layer one 16-byte word group, tile m
+// in half (m & 1) of dword (m >> 1), accumulator register r at bit 15 - r of that half.
+//   forward : bit = (pre-activation > 0), gathered with one subtract + one v_alignbit per register;
+//   backward: dZ[r] = dH[r] AND (0 - bit) before the conversion to the operand type.
+constexpr int kMaskBytes = kFragBytes;       // per sample tile and masked layer: 64 lanes x 16 B
+
+__device__ __forceinline__ uint32_t relu_bits(const f32x16& v) {
+    uint32_t bits = 0;
+    float t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float f = v[r];
+        // t = 0 - f: sign(t) = 1 exactly when f > 0 (0 - 0 = +0);  bits = (bits << 1) | sign(t).
+        // One asm statement per register keeps t a single short-lived scratch register (written as plain C++ the
+        // compiler computed all 16 differences first and spilled: the saving forward sits at the 256-register limit).
+        asm volatile("v_sub_f32 %1, 0, %2\n\tv_alignbit_b32 %0, %0, %1, 31" : "+v"(bits), "=&v"(t) : "v"(f));
+    }
+    return bits & 0xffffu;
 }
 
-template <class Mode> struct Masked;
-template <class V8, class Mode16>
-struct Masked16 {
-    typedef typename Mode16::Act Act;
-    __device__ static __forceinline__ Act apply(const f32x16& v, const Act& x) {
-        Act o = Mode16::template to_act<false>(v);
+template <int M>
+__device__ __forceinline__ void put_bits(i32x4& w, uint32_t bits16) {
+    if constexpr ((M & 1) == 0) w[M >> 1] = (int)bits16;           // the even tile of a dword comes first and initialises it
+    else w[M >> 1] |= (int)(bits16 << 16);
+}
+
+template <class Mode, int M>
+__device__ __forceinline__ typename Mode::Act masked_act(const f32x16& v, const i32x4& w) {
+    const uint32_t word = (uint32_t)w[M >> 1];
+    f32x16 o;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            i32x4 q = __builtin_bit_cast(i32x4, o.f[s]);
-            const i32x4 xi = __builtin_bit_cast(i32x4, x.f[s]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) q[j] &= nonzero_halves(xi[j]);
-            o.f[s] = __builtin_bit_cast(V8, q);
-        }
-        return o;
+    for (int r = 0; r < 16; ++r) {
+        constexpr int kBase = 16 * (M & 1) + 15;
+        const int keep = ((int)(word << (31 - (kBase - r)))) >> 31;       // 0 or -1: sign-extended bit
+        const float f = v[r];     // a named scalar: __builtin_bit_cast applied directly to the vector-element expression read element 0
+        o[r] = __builtin_bit_cast(float, __builtin_bit_cast(int, f) & keep);
     }
-};
-template <> struct Masked<ModeBF16> : Masked16<bf16x8, ModeBF16> {};
-template <> struct Masked<ModeF16> : Masked16<f16x8, ModeF16> {};
-template <>
-struct Masked<ModeF32> {
-    typedef ModeF32::Act Act;
-    __device__ static __forceinline__ Act apply(const f32x16& v, const Act& x) {
-        Act o;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o.r[r] = x.r[r] > 0.0f ? v[r] : 0.0f;
-        return o;
-    }
-};
+    return Mode::template to_act<false>(o);
+}
 
 // T = X^T through the matrix core (header comment).  Result: lane (c, h) register r = X[feature c][sample row(r, h)].
 template <class Mode> struct Transposer;

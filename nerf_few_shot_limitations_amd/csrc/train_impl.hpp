@@ -35,6 +35,7 @@ struct TrainKArgs {
     char* ctx;                // saved tensors
     int64_t slot_off[kMaxSlots];
     int slot_tiles[kMaxSlots];
+    int64_t mask_off[kMaxMaskSlots];   // ReLU-mask bit planes: kMaskBytes per sample tile each
 };
 
 // ---- host-side helpers shared by train_v1.hip / train_v2.hip -------------------------------------------------
@@ -53,6 +54,11 @@ inline bool fill_slots(const TrainDev& t, int mode, int64_t n, TrainKArgs& k, st
         k.slot_tiles[i] = t.slot_tiles[i];
         off += nt * t.slot_tiles[i] * tile_bytes_of(mode);
     }
+    if (t.n_mask_slots < 0 || t.n_mask_slots > kMaxMaskSlots) { err = "training plan: too many masked layers"; return false; }
+    for (int i = 0; i < t.n_mask_slots; ++i) {
+        k.mask_off[i] = off;
+        off += nt * kFragBytes;
+    }
     return true;
 }
 
@@ -66,6 +72,10 @@ inline bool check_train_common(const DeviceNet& net, const TrainDev& t, int mode
 
 // dW/db of every Linear from the saved tensors (defined in train_v1.hip; network independent)
 int launch_weight_grad(const DeviceNet& net, const TrainDev& t, int mode, const TrainKArgs& k, float* grad, hipStream_t s, std::string& err);
+
+__device__ __forceinline__ i32x4* mask_ptr(const TrainKArgs& P, int mslot, int64_t st, int lane) {
+    return (i32x4*)(P.ctx + P.mask_off[mslot] + st * (int64_t)kMaskBytes + lane * 16);
+}
 
 template <class Mode>
 __device__ __forceinline__ char* tile_ptr(const TrainKArgs& P, int slot, int64_t st, int t, int lane) {
@@ -114,17 +124,26 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_kernel(const TrainKA
                 enc[t][0] = Mode::template to_act<false>(e[t]);
                 IO::store(tile_ptr<Mode>(P, 0, st, t, lane), enc[t][0]);
             }
+            i32x4 mw;
             dense<Mode, KT0, HT, 1>(pipe, bias, h, enc, [&](auto m_, f32x16(&acc)[1]) {
-                constexpr int m = decltype(m_)::value;
-                A[m][0] = Mode::template to_act<true>(acc[0]);
+                constexpr int m = decltype(m_)::value;                A[m][0] = Mode::template to_act<true>(acc[0]);
+                __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
+
+                put_bits<m>(mw, relu_bits(acc[0]));
                 IO::store(tile_ptr<Mode>(P, 1, st, m, lane), A[m][0]);
+                if constexpr (m == HT - 1) *mask_ptr(P, 0, st, lane) = mw;
             });
         }
+        // trunk layer writing activation slot `slot` (and the mask plane slot - 1)
         auto layer = [&](const Act (&in)[HT][1], Act (&out)[HT][1], int slot, int boff) {
+            i32x4 mw;
             dense<Mode, HT, HT, 1>(pipe, bias + boff, h, in, [&](auto m_, f32x16(&acc)[1]) {
-                constexpr int m = decltype(m_)::value;
-                out[m][0] = Mode::template to_act<true>(acc[0]);
+                constexpr int m = decltype(m_)::value;                out[m][0] = Mode::template to_act<true>(acc[0]);
+                __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
+
+                put_bits<m>(mw, relu_bits(acc[0]));
                 IO::store(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
+                if constexpr (m == HT - 1) *mask_ptr(P, slot - 1, st, lane) = mw;
             });
         };
         int boff = 32 * HT, slot = 2;
@@ -152,8 +171,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_kernel(const TrainKA
 // ---------------------------------------------------------------------------------------------
 // backward chain
 // ---------------------------------------------------------------------------------------------
-// ReLU masks: the saved activation tile of the layer below is needed in the epilogue of every output tile; the loads
-// run kMaskAhead tiles ahead of their use (HBM latency is several tile times)
+// ReLU' comes from the forward's bit planes (train_core.hpp), 16 B per lane and layer, loaded one layer ahead
 template <class Mode, int WAVES, int LP>
 __global__ void __launch_bounds__(WAVES * 64) train_backward_kernel(const TrainKArgs P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -162,7 +180,6 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_kernel(const TrainK
     typedef typename Mode::Act Act;
     typedef ActIO<Mode> IO;
     constexpr int HT = 8;
-    constexpr int kMaskAhead = 4;
 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -176,12 +193,8 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_kernel(const TrainK
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         const int64_t st = tile * WAVES + wave;
         const int64_t raw = st * 32 + c;
-        // masks of layer L (slot L, L = n .. 1), tiles 0..7, as one linear sequence q = (n - L) * 8 + m
-        Act mk[kMaskAhead];
-        const int n_mask = 8 * n;
-        auto mask_ptr = [&](int q) { return tile_ptr<Mode>(P, n - (q >> 3), st, q & 7, lane); };
-#pragma unroll
-        for (int q = 0; q < kMaskAhead; ++q) mk[q] = IO::template load<Act>(mask_ptr(q));
+        // ReLU' bits of trunk layer L (mask plane L - 1), loaded one layer ahead of their use
+        i32x4 mcur = *mask_ptr(P, n - 1, st, lane), mnext = mcur;
 
         Act G[1][1];
         {   // d out4 -> d [rgb logits, sigma]: rows 0..3 of one operand tile (registers 0..3 of lane half 0)
@@ -198,26 +211,27 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_kernel(const TrainK
             IO::store(tile_ptr<Mode>(P, 2 * n + 1, st, 0, lane), G[0][0]);
         }
         Act A[HT][1], B[HT][1];
-        int q0 = 0;       // mask sequence index of tile 0 of the layer being produced
         auto epilogue = [&](auto m_, f32x16(&acc)[1], Act (&out)[HT][1], int slot_dz) {
             constexpr int m = decltype(m_)::value;
-            out[m][0] = Masked<Mode>::apply(acc[0], mk[m % kMaskAhead]);
-            const int qn = q0 + m + kMaskAhead;
-            if (qn < n_mask) mk[m % kMaskAhead] = IO::template load<Act>(mask_ptr(qn));
+            out[m][0] = masked_act<Mode, m>(acc[0], mcur);
             IO::store(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
         };
-        static_assert(HT % kMaskAhead == 0, "mask ring indexed by the tile number inside a layer");
+        int below = n - 2;            // mask plane of the layer under the one being produced
+        auto prefetch = [&]() { if (below >= 0) mnext = *mask_ptr(P, below, st, lane); --below; };
         // head^T -> dZ of layers.{n-1}
+        prefetch();
         dense<Mode, 1, HT, 1>(pipe, zero_bias, h, G, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, A, 2 * n); });
-        q0 += 8;
+        mcur = mnext;
         // layers.l^T, l = n-1 .. 1: dZ_l -> dZ_{l-1}
         const int hidden = n - 1;
         int slot = 2 * n - 1;
         for (int p = 0; p < hidden / 2; ++p) {
+            prefetch();
             dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, B, slot); });
-            --slot; q0 += 8;
+            mcur = mnext; --slot;
+            prefetch();
             dense<Mode, HT, HT, 1>(pipe, zero_bias, h, B, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, A, slot); });
-            --slot; q0 += 8;
+            mcur = mnext; --slot;
         }
         if (hidden & 1) {
             dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { epilogue(m_, acc, B, slot); });

@@ -49,17 +49,25 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
                 enc[t][0] = e1[t];
                 IO::store(tile_ptr<Mode>(P, 0, st, t, lane), e1[t]);
             }
+            i32x4 mw;
             dense<Mode, KT0, HT, 1>(pipe, bias, h, enc, [&](auto m_, f32x16(&acc)[1]) {
-                constexpr int m = decltype(m_)::value;
-                A[m][0] = Mode::template to_act<true>(acc[0]);
+                constexpr int m = decltype(m_)::value;                A[m][0] = Mode::template to_act<true>(acc[0]);
+                __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
+
+                put_bits<m>(mw, relu_bits(acc[0]));
                 IO::store(tile_ptr<Mode>(P, 1, st, m, lane), A[m][0]);
+                if constexpr (m == HT - 1) *mask_ptr(P, 0, st, lane) = mw;
             });
         }
         auto layer = [&](const Act (&in)[HT][1], Act (&out)[HT][1], int slot, int boff) {
+            i32x4 mw;
             dense<Mode, HT, HT, 1>(pipe, bias + boff, h, in, [&](auto m_, f32x16(&acc)[1]) {
-                constexpr int m = decltype(m_)::value;
-                out[m][0] = Mode::template to_act<true>(acc[0]);
+                constexpr int m = decltype(m_)::value;                out[m][0] = Mode::template to_act<true>(acc[0]);
+                __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
+
+                put_bits<m>(mw, relu_bits(acc[0]));
                 IO::store(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
+                if constexpr (m == HT - 1) *mask_ptr(P, slot - 1, st, lane) = mw;
             });
         };
         float dens_raw = 0.0f, logit[3];
@@ -86,15 +94,23 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
                 IO::store(tile_ptr<Mode>(P, n + 1, st, HT, lane), t1[0]);
             }
             Act c0[HT / 2][1], c1[HT / 4][1];
+            i32x4 mw = {};
             dense<Mode, HT + 1, HT / 2, 1>(pipe, bias + boff + 32 + 32 * HT, h, in9, [&](auto m_, f32x16(&acc)[1]) {
-                constexpr int m = decltype(m_)::value;
-                c0[m][0] = Mode::template to_act<true>(acc[0]);
+                constexpr int m = decltype(m_)::value;                c0[m][0] = Mode::template to_act<true>(acc[0]);
+                __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
+
+                put_bits<m>(mw, relu_bits(acc[0]));
                 IO::store(tile_ptr<Mode>(P, n + 2, st, m, lane), c0[m][0]);
+                if constexpr (m == HT / 2 - 1) *mask_ptr(P, n, st, lane) = mw;
             });
+            i32x4 mw1 = {};
             dense<Mode, HT / 2, HT / 4, 1>(pipe, bias + boff + 32 + 32 * HT + 16 * HT, h, c0, [&](auto m_, f32x16(&acc)[1]) {
-                constexpr int m = decltype(m_)::value;
-                c1[m][0] = Mode::template to_act<true>(acc[0]);
+                constexpr int m = decltype(m_)::value;                c1[m][0] = Mode::template to_act<true>(acc[0]);
+                __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
+
+                put_bits<m>(mw1, relu_bits(acc[0]));
                 IO::store(tile_ptr<Mode>(P, n + 3, st, m, lane), c1[m][0]);
+                if constexpr (m == HT / 4 - 1) *mask_ptr(P, n + 1, st, lane) = mw1;
             });
             f32x16 rgb[1];
             dense_head<Mode, HT / 4, 1>(pipe, bias + boff + 32 + 32 * HT + 16 * HT + 8 * HT, h, c1, rgb);
@@ -130,7 +146,6 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v2_kernel(const Tra
     typedef typename Mode::Act Act;
     typedef ActIO<Mode> IO;
     constexpr int HT = 8;
-    constexpr int kMaskAhead = 4;
 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -144,27 +159,14 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v2_kernel(const Tra
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         const int64_t st = tile * WAVES + wave;
         const int64_t raw = st * 32 + c;
-        // ReLU masks in the order the chain needs them: colour layer 2 output (2 tiles), colour layer 0 output (4),
-        // then the trunk activations of layers n .. 1 (8 each); kMaskAhead tiles ahead of their use
-        Act mk[kMaskAhead];
-        const int n_mask = 6 + 8 * n;
-        auto mask_ptr = [&](int q) {
-            if (q < 2) return tile_ptr<Mode>(P, n + 3, st, q, lane);
-            if (q < 6) return tile_ptr<Mode>(P, n + 2, st, q - 2, lane);
-            return tile_ptr<Mode>(P, n - ((q - 6) >> 3), st, (q - 6) & 7, lane);
-        };
-#pragma unroll
-        for (int q = 0; q < kMaskAhead; ++q) mk[q] = IO::template load<Act>(mask_ptr(q));
-        // QOFF = (sequence index of the layer's first tile) mod kMaskAhead: the ring slot of tile m is static
-        auto masked = [&](auto qoff_, auto m_, f32x16(&acc)[1], auto& out, int slot_dz, int q_first) {
-            constexpr int m = decltype(m_)::value, ring = (decltype(qoff_)::value + m) % kMaskAhead;
-            out[m][0] = Masked<Mode>::apply(acc[0], mk[ring]);
-            const int qn = q_first + m + kMaskAhead;
-            if (qn < n_mask) mk[ring] = IO::template load<Act>(mask_ptr(qn));
+        // ReLU' bit planes (train_core.hpp) in the order the chain needs them: colour layer 2 (plane n+1), colour layer 0
+        // (plane n), trunk layers n-1 .. 0; each is loaded while the layer before it runs
+        i32x4 mcur = *mask_ptr(P, n + 1, st, lane), mnext = *mask_ptr(P, n, st, lane);
+        auto masked = [&](auto m_, f32x16(&acc)[1], auto& out, int slot_dz) {
+            constexpr int m = decltype(m_)::value;
+            out[m][0] = masked_act<Mode, m>(acc[0], mcur);
             IO::store(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
         };
-        typedef std::integral_constant<int, 0> Q0;
-        typedef std::integral_constant<int, 2> Q2;
 
         Act in9[HT + 1][1];
         {
@@ -187,8 +189,11 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v2_kernel(const Tra
                 in9[HT][0] = Mode::template to_act<false>(e2);
                 IO::store(tile_ptr<Mode>(P, 2 * n + 4, st, 0, lane), in9[HT][0]);
             }
-            dense<Mode, 1, HT / 4, 1>(pipe, zero_bias, h, G, [&](auto m_, f32x16(&acc)[1]) { masked(Q0{}, m_, acc, d1, 2 * n + 7, 0); });
-            dense<Mode, HT / 4, HT / 2, 1>(pipe, zero_bias, h, d1, [&](auto m_, f32x16(&acc)[1]) { masked(Q2{}, m_, acc, d0, 2 * n + 6, 2); });
+            dense<Mode, 1, HT / 4, 1>(pipe, zero_bias, h, G, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, d1, 2 * n + 7); });
+            mcur = mnext;
+            mnext = *mask_ptr(P, n - 1, st, lane);
+            dense<Mode, HT / 4, HT / 2, 1>(pipe, zero_bias, h, d1, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, d0, 2 * n + 6); });
+            mcur = mnext;
             dense<Mode, HT / 2, HT, 1>(pipe, zero_bias, h, d0, [&](auto m_, f32x16(&acc)[1]) {          // d feature_vec: no activation to undo
                 constexpr int m = decltype(m_)::value;
                 in9[m][0] = Mode::template to_act<false>(acc[0]);
@@ -196,20 +201,24 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v2_kernel(const Tra
             });
         }
         Act A[HT][1], B[HT][1];
-        int q_first = 6;
+        int below = n - 2;            // mask plane of the trunk layer under the one being produced
+        auto prefetch = [&]() { if (below >= 0) mnext = *mask_ptr(P, below, st, lane); --below; };
         // [feature_head | density_head]^T -> dZ of density_layers.{n-1}
-        dense<Mode, HT + 1, HT, 1>(pipe, zero_bias, h, in9, [&](auto m_, f32x16(&acc)[1]) { masked(Q2{}, m_, acc, A, 2 * n + 3, q_first); });
-        q_first += 8;
+        prefetch();
+        dense<Mode, HT + 1, HT, 1>(pipe, zero_bias, h, in9, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, A, 2 * n + 3); });
+        mcur = mnext;
         const int hidden = n - 1;
         int slot = 2 * n + 2;
         for (int p = 0; p < hidden / 2; ++p) {
-            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { masked(Q2{}, m_, acc, B, slot, q_first); });
-            --slot; q_first += 8;
-            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, B, [&](auto m_, f32x16(&acc)[1]) { masked(Q2{}, m_, acc, A, slot, q_first); });
-            --slot; q_first += 8;
+            prefetch();
+            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, B, slot); });
+            mcur = mnext; --slot;
+            prefetch();
+            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, B, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, A, slot); });
+            mcur = mnext; --slot;
         }
         if (hidden & 1) {
-            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { masked(Q2{}, m_, acc, B, slot, q_first); });
+            dense<Mode, HT, HT, 1>(pipe, zero_bias, h, A, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, B, slot); });
         }
     }
     pipe.drain();

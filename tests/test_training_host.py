@@ -57,7 +57,9 @@ def train_plan(L, variant, p, n_layers):
         j["row_b"] = [next(it) for _ in range(32 * j["MT"])]
         j["col"] = [next(it) for _ in range(32 * j["KT"])]
         jobs.append(j)
+    n_mask = next(it)
     assert next(it, None) is None
+    assert n_mask == (n_layers if variant == "v1" else n_layers + 2)
     return names, slot_tiles, jobs
 
 

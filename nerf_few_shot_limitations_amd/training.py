@@ -319,6 +319,38 @@ class Adam:
 
 
 # ---------------------------------------------------------------------------------------------
+# data-parallel training: one collective per step
+# ---------------------------------------------------------------------------------------------
+def _all_reduce_mean(t, group, average=True):
+    """In-place all-reduce of a device vector.  RCCL (backend "nccl") reduces device memory directly; under gloo (CPU
+    rehearsals, one-GPU test boxes) the vector takes the host round trip gloo needs."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        t.div_(dist.get_world_size(group))
+    return t
+
+
+def all_reduce_gradients(model, group=None, average=True):
+    """Sum (or average) the gradients of all ranks before optimizer.step().  The gradients of a NeRFMLP live in ONE flat
+    vector (see _grad_target), so data-parallel training costs a single all-reduce of nrf_param_count floats
+    (1.9 MB for the 8x256 network: one RCCL ring step over xGMI) instead of one per parameter.  Rays shard over the ranks
+    (every rank renders its own rays of the batch: no exchange inside the path); call between backward() and step()."""
+    fp = model.flat_params()
+    fg = getattr(model, "_flat_grad", None)
+    ps = fp.params()
+    if fg is None or any(p.grad is None for p in ps) or any(p.grad.data_ptr() != fg.data_ptr() + 4 * off for p, off in zip(ps, fp.offsets)):
+        raise RuntimeError("all_reduce_gradients: the parameters' .grad are not the flat gradient vector of this module "
+                           "(call it right after loss.backward())")
+    return _all_reduce_mean(fg, group, average)
+
+
+# ---------------------------------------------------------------------------------------------
 # one optimisation step without autograd in between
 # ---------------------------------------------------------------------------------------------
 class FusedStep:
@@ -334,10 +366,16 @@ class FusedStep:
         loss = step(points, z_vals, rays_d, target, dirs=dirs)    # V2: points (R*S, 3), dirs (R*S, 3)
     """
 
-    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, rgb_weight=1.0, white_bkgd=False):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, rgb_weight=1.0, white_bkgd=False,
+                 process_group=None, data_parallel=False):
+        """data_parallel=True (inside an initialised torch.distributed job): every rank passes ITS shard of the ray batch
+        (equal sizes), the flat gradient vector is averaged over the ranks with one all-reduce before Adam, and the
+        returned loss is this rank's."""
         if model.net not in (L.NRF_NET_V1, L.NRF_NET_V2):
             raise NotImplementedError("FusedStep: V1 and V2 models only")
         self.model = model
+        self.data_parallel = bool(data_parallel)
+        self.group = process_group
         self.opt = Adam(model, lr, betas, eps, weight_decay)
         self.rgb_weight = float(rgb_weight)
         self.white = int(bool(white_bkgd))
@@ -402,6 +440,8 @@ class FusedStep:
                 L.check(lib.nrf_mlp_backward(h, mode, L.ptr(rgb), L.ptr(den), L.ptr(g_rgb), L.ptr(g_den), n, ctx, self.nbytes, L.ptr(self.grad), st))
             else:
                 L.check(lib.nrf_mlp_backward_v1(h, mode, L.ptr(o4), L.ptr(d4), n, ctx, self.nbytes, L.ptr(self.grad), st))
+            if self.data_parallel:
+                _all_reduce_mean(self.grad, self.group)
             opt = self.opt
             fp, flat = opt._buffers()
             opt.step_count += 1

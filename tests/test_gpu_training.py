@@ -628,3 +628,56 @@ def test_fused_step_equals_autograd_route(N, net, mode):
     # steps turn gradient noise around 0 into +-lr -- the 16-bit modes then see different operand roundings
     assert np.allclose(ref_losses, got, rtol=1e-5 if mode == "f32" else 2e-3, atol=1e-7), (ref_losses, got)
     assert got[-1] < got[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel training: rays shard over the ranks, ONE all-reduce of the flat gradient vector per step
+# ---------------------------------------------------------------------------------------------
+def _run_dp(route, steps, tmp_path):
+    import os, socket, subprocess, sys
+    out = str(tmp_path / f"dp_{route}.npy")
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "dp_train_worker.py"), route, out, str(steps)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return np.load(out)
+
+
+@pytest.mark.parametrize("route", ["autograd_sgd", "fused"])
+def test_data_parallel_two_ranks_equal_one_rank_on_the_whole_batch(N, route, tmp_path):
+    """Two ranks (gloo here: the test box has one GPU, which both ranks share; RCCL on a real node), each on half of the
+    rays, averaged gradients: the parameters after 3 steps equal a single process training on the whole batch.  SGD for the
+    autograd route (linear in the gradient); Adam for FusedStep, compared with the looser bound its sign-like first
+    steps allow (see test_training_steps_match_cpu_reference_loop)."""
+    import importlib.util, os
+    from nerf_few_shot_limitations_amd.training import Adam, FusedStep
+    steps = 3
+    got = _run_dp(route, steps, tmp_path)
+    spec = importlib.util.spec_from_file_location("dp_worker", os.path.join(os.path.dirname(__file__), "dp_train_worker.py"))
+    worker = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(worker)
+    R, S = 128, 16
+    x, z, rd, tgt = worker.batch(R, S)
+    model, _ = make_model(N, "f32", scene="solid")
+    xs, zs, rds, tgts = x.reshape(-1, 63).cuda(), z.cuda(), rd.cuda(), tgt.cuda()
+    if route == "fused":
+        step = FusedStep(model, lr=1e-2)
+        for _ in range(steps):
+            step(xs, zs, rds, tgts)
+        bound = 2.5 * 1e-2 * steps
+    else:
+        opt = torch.optim.SGD(model.parameters(), lr=1e-2)
+        for _ in range(steps):
+            opt.zero_grad()
+            pred = N.volume_render_radiance(model(xs).view(R, 1, S, 4), zs.view(R, 1, S), rds.view(R, 1, 3)).view(R, 3)
+            torch.nn.functional.mse_loss(pred, tgts).backward()
+            opt.step()
+        bound = 1e-5
+    ref = model.flat_params().flat.detach().cpu().numpy()
+    assert np.abs(got - ref).max() < bound, np.abs(got - ref).max()
+    if route == "fused":
+        assert np.mean(np.abs(got - ref) > 1e-4) < 0.02          # all but the elements whose gradient is noise around 0

@@ -66,3 +66,34 @@ def test_gather_frame_gloo(world, n_rays, tile_rays):
         assert p.exitcode == 0
     res = dict(q.get(timeout=10) for _ in range(world))
     assert res == {r: True for r in range(world)}
+
+
+# ---- data-parallel training: the gradient exchange (training.py), rehearsed on CPU tensors -------------------------
+def _grad_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nerf_few_shot_limitations_amd.training import _all_reduce_mean
+        g = torch.arange(1000, dtype=torch.float32) * (rank + 1)          # this rank's flat gradient vector
+        _all_reduce_mean(g, None)
+        want = torch.arange(1000, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+        s = torch.arange(8, dtype=torch.float32) + rank
+        _all_reduce_mean(s, None, average=False)
+        q.put((rank, bool(torch.allclose(g, want)) and bool(torch.equal(s, torch.arange(8, dtype=torch.float32) * world + sum(range(world))))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_flat_gradient_all_reduce_gloo(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(r, True) for r in range(world)]

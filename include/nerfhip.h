@@ -209,8 +209,8 @@ int nrf_abi_sizeof(int which);
 /* ------------------------------------------------------------------------
  * Training path: what loss.backward() and
  * optimizer.step() of src/training/train.py:282-288 run through.  Built for
- * NRF_NET_V1 (nerf_model.NeRFMLP, the network of train_minimal.py:28) and
- * NRF_NET_V2 (train.py's model with use_dino=False).
+ * NRF_NET_V1 (nerf_model.NeRFMLP, the network of train_minimal.py:28),
+ * NRF_NET_V2 (train.py's model with use_dino=False) and NRF_NET_V3 (use_dino=True).
  *
  * Parameters and gradients travel as ONE flat fp32 device vector: the Linears
  * in state_dict order, each weight (out_f*in_f, row-major) followed by its
@@ -244,8 +244,11 @@ int nrf_mlp_backward_v1(nrf_model* m, int mma_mode, const float* out4, const flo
 /* The same pair for NRF_NET_V2 (train.py:229 `rgb, density = self.nerf_model(positions, directions, None)` with grad
  * enabled; nerf_mlp.py:134-158 without the DINO branch).  rgb (n,3) / density (n,1) are written by the forward and
  * read again by the backward (sigmoid', relu'); g_rgb / g_density are dL/d of them.  No gradient with respect to
- * positions or directions.  NRF_NET_V3 is not built (NRF_EUNSUPPORTED). */
-int nrf_mlp_forward_train(nrf_model* m, int mma_mode, const float* positions, const float* directions, int64_t n,
+ * positions, directions or the DINO features.  NRF_NET_V3 (nerf_mlp.py:134-158 with lora_dino.py:171-193: the fusion
+ * block runs twice on the same weights, gated by a 2-way softmax) takes the per-sample features as `dino`; up to 8 trunk
+ * layers. */
+int nrf_mlp_forward_train(nrf_model* m, int mma_mode, const float* positions, const float* directions,
+                          const float* dino /* NRF_NET_V3: (n, dino_dim) per-sample features, else NULL */, int64_t n,
                           float* rgb, float* density, void* ctx, int64_t ctx_bytes, void* stream);
 int nrf_mlp_backward(nrf_model* m, int mma_mode, const float* rgb, const float* density,
                      const float* g_rgb, const float* g_density, int64_t n,

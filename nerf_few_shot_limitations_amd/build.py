@@ -20,7 +20,7 @@ OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libnerfhip.so")
 INCLUDE = os.path.join(os.path.dirname(PKG), "include")
 
-SOURCES = ["fused_v1.hip", "fused_v2.hip", "fused_v3.hip", "fused_v3w.hip", "fused_kernels.hip", "train_v1.hip", "train_v2.hip", "staged_kernels.hip", "api.cpp", "packing.cpp"]
+SOURCES = ["fused_v1.hip", "fused_v2.hip", "fused_v3.hip", "fused_v3w.hip", "fused_kernels.hip", "train_v1.hip", "train_v2.hip", "train_v3.hip", "staged_kernels.hip", "api.cpp", "packing.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-fno-gpu-rdc", "-ffp-contract=off", f"-I{INCLUDE}"]
 

@@ -201,6 +201,7 @@ int ensure_train(nrf_model* m) {
     m->train.n_slots = (int)m->tplan.slot_tiles.size();
     for (int i = 0; i < m->train.n_slots; ++i) m->train.slot_tiles[i] = m->tplan.slot_tiles[i];
     m->train.n_mask_slots = m->tplan.n_mask_slots;
+    m->train.aux_floats = m->tplan.aux_floats;
     m->train.n_params = m->layout.total;
     m->train_ready = true;
     return NRF_OK;
@@ -510,20 +511,23 @@ int nrf_mlp_backward_v1(nrf_model* m, int mma_mode, const float* out4, const flo
     return r == NRF_OK ? NRF_OK : fail(r, err);
 }
 
-int nrf_mlp_forward_train(nrf_model* m, int mma_mode, const float* positions, const float* directions, int64_t n, float* rgb, float* density,
-                          void* ctx, int64_t ctx_bytes, void* stream) {
+int nrf_mlp_forward_train(nrf_model* m, int mma_mode, const float* positions, const float* directions, const float* dino, int64_t n, float* rgb,
+                          float* density, void* ctx, int64_t ctx_bytes, void* stream) {
     if (!m) return fail(NRF_EINVAL, "model is NULL");
     if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
     if (n == 0) return NRF_OK;
     if (!positions || !directions || !rgb || !density || !ctx) return fail(NRF_EINVAL, "null pointer");
-    if (m->arch.net != NRF_NET_V2) return fail(NRF_EUNSUPPORTED, "nrf_mlp_forward_train is built for NRF_NET_V2 (V1: nrf_mlp_forward_train_v1)");
+    if (m->arch.net == NRF_NET_V1) return fail(NRF_EINVAL, "V1 models take encoded inputs: nrf_mlp_forward_train_v1");
+    if (m->arch.net == NRF_NET_V3 && !dino) return fail(NRF_EINVAL, "V3 needs per-sample dino features");
     DeviceGuard guard(m->device);
     if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
     const int rc = ensure_train(m);
     if (rc != NRF_OK) return rc;
     if (ctx_bytes < nrf::train_ctx_bytes(m->train, mma_mode, n)) return fail(NRF_EINVAL, "context buffer smaller than nrf_train_context_bytes");
     std::string err;
-    const int r = nrf::launch_train_forward_v2(m->net, m->train, mma_mode, positions, directions, n, rgb, density, ctx, (hipStream_t)stream, err);
+    const int r = m->arch.net == NRF_NET_V3
+        ? nrf::launch_train_forward_v3(m->net, m->train, mma_mode, positions, directions, dino, n, rgb, density, ctx, (hipStream_t)stream, err)
+        : nrf::launch_train_forward_v2(m->net, m->train, mma_mode, positions, directions, n, rgb, density, ctx, (hipStream_t)stream, err);
     return r == NRF_OK ? NRF_OK : fail(r, err);
 }
 
@@ -533,7 +537,7 @@ int nrf_mlp_backward(nrf_model* m, int mma_mode, const float* rgb, const float* 
     if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
     if (n == 0) return NRF_OK;
     if (!rgb || !density || !g_rgb || !g_density || !ctx || !flat_grad) return fail(NRF_EINVAL, "null pointer");
-    if (m->arch.net != NRF_NET_V2) return fail(NRF_EUNSUPPORTED, "nrf_mlp_backward is built for NRF_NET_V2 (V1: nrf_mlp_backward_v1)");
+    if (m->arch.net == NRF_NET_V1) return fail(NRF_EINVAL, "V1 models: nrf_mlp_backward_v1");
     DeviceGuard guard(m->device);
     if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
     const int rc = ensure_train(m);
@@ -542,7 +546,9 @@ int nrf_mlp_backward(nrf_model* m, int mma_mode, const float* rgb, const float* 
     if (!m->bfresh[mma_mode])
         return fail(NRF_EINVAL, "backward weights of this mode are older than the parameters: call nrf_model_update_device (with this mode) first");
     std::string err;
-    const int r = nrf::launch_train_backward_v2(m->net, m->train, mma_mode, rgb, density, g_rgb, g_density, n, ctx, flat_grad, (hipStream_t)stream, err);
+    const int r = m->arch.net == NRF_NET_V3
+        ? nrf::launch_train_backward_v3(m->net, m->train, mma_mode, rgb, density, g_rgb, g_density, n, ctx, flat_grad, (hipStream_t)stream, err)
+        : nrf::launch_train_backward_v2(m->net, m->train, mma_mode, rgb, density, g_rgb, g_density, n, ctx, flat_grad, (hipStream_t)stream, err);
     return r == NRF_OK ? NRF_OK : fail(r, err);
 }
 

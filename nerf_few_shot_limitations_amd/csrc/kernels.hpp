@@ -73,7 +73,7 @@ int launch_forward(const DeviceNet& net, int mma_mode, const float* pos, const f
 
 // ---- training path (train_v1.hip) -------------------------------------------------
 constexpr int kMaxSlots = 40;
-constexpr int kMaxJobs = 20;
+constexpr int kMaxJobs = 24;
 constexpr int kMaxMaskSlots = 20;
 constexpr int kMapStride = 3 * 320;      // per weight-gradient job: row_w[320] | row_b[320] | col[320]
 
@@ -84,6 +84,7 @@ struct TrainDev {
     int n_slots;
     int slot_tiles[kMaxSlots];  // feature tiles per saved-tensor slot
     int n_mask_slots;           // ReLU-mask bit planes (one per masked layer)
+    int aux_floats;             // extra fp32 values saved per sample (V3: the softmax gate)
     int n_jobs;
     int job_x_slot[kMaxJobs], job_dz_slot[kMaxJobs], job_KT[kMaxJobs], job_MT[kMaxJobs], job_x_first[kMaxJobs];
     int64_t n_params;
@@ -98,6 +99,10 @@ int launch_train_backward(const DeviceNet& net, const TrainDev& t, int mma_mode,
 int launch_train_forward_v2(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* pos, const float* dir, int64_t n, float* rgb,
                             float* density, void* ctx, hipStream_t s, std::string& err);
 int launch_train_backward_v2(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* rgb, const float* density,
+                             const float* g_rgb, const float* g_density, int64_t n, void* ctx, float* grad, hipStream_t s, std::string& err);
+int launch_train_forward_v3(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* pos, const float* dir, const float* dino, int64_t n,
+                            float* rgb, float* density, void* ctx, hipStream_t s, std::string& err);
+int launch_train_backward_v3(const DeviceNet& net, const TrainDev& t, int mma_mode, const float* rgb, const float* density,
                              const float* g_rgb, const float* g_density, int64_t n, void* ctx, float* grad, hipStream_t s, std::string& err);
 int launch_repack(const float* flat, const int32_t* src, int64_t n_elems, int mma_mode, void* out, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,

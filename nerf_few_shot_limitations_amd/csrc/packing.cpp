@@ -308,9 +308,10 @@ PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin
 // Saved-tensor slots: train_impl.hpp (V1), train_v2_impl.hpp (V2).
 bool make_backward_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, NetPlan& plan, std::string& err) {
     plan = NetPlan();
-    if (a.net != NRF_NET_V1 && a.net != NRF_NET_V2) { err = "the training path is built for V1 (nerf_model.NeRFMLP) and V2 (DensityMLP + ColorMLP)"; return false; }
+    if (a.net != NRF_NET_V1 && a.net != NRF_NET_V2 && a.net != NRF_NET_V3) { err = "unknown network family"; return false; }
     if (a.hidden != 256 || (int)lin.size() != expected_linears(a)) { err = "backward plan: unexpected architecture"; return false; }
     const int n = a.n_layers, H = a.hidden, HT = H / 32;
+    const int b = a.net == NRF_NET_V3 ? 5 : 0;                     // index of the first trunk Linear
     auto first_cols = [&](int count, int MT) { std::vector<int> r(32 * MT, -1); for (int i = 0; i < count; ++i) r[i] = i; return r; };
     auto transposed = [&](int li, int out_rows, int KT, int in_cols, int MT) {      // lin[li]^T: K = its rows, outputs = its first in_cols columns
         LayerPlan L; L.transposed = true; L.KT = KT; L.MT = MT; L.krow.assign(32 * KT, {-1, 0});
@@ -325,14 +326,30 @@ bool make_backward_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, N
         L.rcol = first_cols(H, HT);
         plan.layers.push_back(std::move(L));
     } else {
-        plan.layers.push_back(transposed(n + 4, 3, 1, H / 4, H / 128));         // color_layers.4^T: 3 -> 64
-        plan.layers.push_back(transposed(n + 3, H / 4, H / 128, H / 2, H / 64));   // color_layers.2^T: 64 -> 128
-        plan.layers.push_back(transposed(n + 2, H / 2, H / 64, H, HT));         // color_layers.0^T, feature columns only: 128 -> 256
-        LayerPlan FD = transposed(n + 1, H, HT + 1, H, HT);                     // [feature_head | density_head]^T: 256 + 1 -> 256
-        FD.krow[H] = {n, 0};
+        plan.layers.push_back(transposed(b + n + 4, 3, 1, H / 4, H / 128));         // color_layers.4^T: 3 -> 64
+        plan.layers.push_back(transposed(b + n + 3, H / 4, H / 128, H / 2, H / 64));   // color_layers.2^T: 64 -> 128
+        plan.layers.push_back(transposed(b + n + 2, H / 2, H / 64, H, HT));         // color_layers.0^T, feature columns only: 128 -> 256
+        LayerPlan FD = transposed(b + n + 1, H, HT + 1, H, HT);                     // [feature_head | density_head]^T: 256 + 1 -> 256
+        FD.krow[H] = {b + n, 0};
         plan.layers.push_back(std::move(FD));
     }
-    for (int l = n - 1; l >= 1; --l) plan.layers.push_back(transposed(l, H, HT, H, HT));   // trunk layer l^T: dZ_l -> dH_{l-1}
+    for (int l = n - 1; l >= 1; --l) plan.layers.push_back(transposed(b + l, H, HT, H, HT));   // trunk layer l^T: dZ_l -> dH_{l-1}
+    if (a.net == NRF_NET_V3) {
+        // below the trunk (train_v3_impl.hpp): trunk layer 0^T, output_proj^T, fusion.2^T, fusion.0^T (second pass: dX is
+        // needed for the gate), attention.2^T, attention.0^T, fusion.2^T again (first pass; its fusion.0 needs no dX)
+        NetPlan fwd;
+        if (!make_plan(a, lin, fwd, err)) return false;
+        const LayerPlan& F0 = fwd.layers[0];                                       // K order of [PE(pos) | dino] in the kernel
+        plan.layers.push_back(transposed(b, H, HT, H, HT));
+        plan.layers.push_back(transposed(4, H, HT, H, HT));
+        plan.layers.push_back(transposed(1, H, HT, H, HT));
+        LayerPlan F0T = transposed(0, H, HT, 0, F0.KT);
+        for (int r = 0; r < 32 * F0.KT; ++r) F0T.rcol[r] = F0.col[r];
+        plan.layers.push_back(std::move(F0T));
+        plan.layers.push_back(transposed(3, 2, 1, H / 4, H / 128));                  // attention.2^T: 2 -> 64
+        plan.layers.push_back(transposed(2, H / 4, H / 128, H, HT));                 // attention.0^T: 64 -> 256
+        plan.layers.push_back(transposed(1, H, HT, H, HT));
+    }
     int off = 0;
     for (auto& L : plan.layers) { L.bias_off = off; off += 32 * L.MT; }
     plan.n_bias = off;
@@ -341,9 +358,9 @@ bool make_backward_plan(const nrf_arch& a, const std::vector<HostLinear>& lin, N
 
 bool make_train_plan(const nrf_arch& a, const NetPlan& fwd, const ParamLayout& lay, TrainPlan& tp, std::string& err) {
     tp = TrainPlan();
-    if (a.net != NRF_NET_V1 && a.net != NRF_NET_V2) { err = "the training path is built for V1 and V2"; return false; }
+    if (a.net != NRF_NET_V1 && a.net != NRF_NET_V2 && a.net != NRF_NET_V3) { err = "unknown network family"; return false; }
     const int n = a.n_layers;
-    const int expect = a.net == NRF_NET_V1 ? n + 1 : n + 5;
+    const int expect = a.net == NRF_NET_V1 ? n + 1 : (a.net == NRF_NET_V2 ? n + 5 : n + 12);
     if ((int)fwd.layers.size() != expect) { err = "train plan: forward plan has an unexpected layer count"; return false; }
     // one job per forward-plan layer (a window of <= 8 input tiles of it)
     auto add_job = [&](const LayerPlan& L, int x_slot, int dz_slot, int x_first, int KT, bool with_bias) {
@@ -370,6 +387,33 @@ bool make_train_plan(const nrf_arch& a, const NetPlan& fwd, const ParamLayout& l
         tp.slot_tiles[2 * n + 1] = 1;
         tp.n_mask_slots = n;                                       // plane l: ReLU of layers.{l}
         for (int l = 0; l <= n; ++l) add_job(fwd.layers[l], l, l < n ? n + 1 + l : 2 * n + 1, 0, fwd.layers[l].KT, true);
+        return true;
+    }
+    if (a.net == NRF_NET_V3) {
+        // slots and planes: train_v3_impl.hpp.  Forward plan layers: 0 F0, 1 F1, 2 A0, 3 A2, 4 F0 (second pass), 5 F1, 6 proj,
+        // 7.. trunk, then density_head, feature_head, colour layers.
+        const int KT0 = fwd.layers[0].KT, D = 11 + n;
+        tp.slot_tiles.assign(23 + 2 * n, 8);
+        tp.slot_tiles[0] = KT0; tp.slot_tiles[3] = 2; tp.slot_tiles[4] = KT0;
+        tp.slot_tiles[8 + n] = 9; tp.slot_tiles[9 + n] = 4; tp.slot_tiles[10 + n] = 2;
+        tp.slot_tiles[D + 2] = 2; tp.slot_tiles[D + 3] = 1;
+        tp.slot_tiles[D + 7 + n] = 1; tp.slot_tiles[D + 9 + n] = 4; tp.slot_tiles[D + 10 + n] = 2; tp.slot_tiles[D + 11 + n] = 1;
+        tp.n_mask_slots = 7 + n;
+        tp.aux_floats = 2;                                           // the gate (w0, w1) per sample
+        add_job(fwd.layers[0], 0, D + 0, 0, KT0, true);              // fusion.0, first pass
+        add_job(fwd.layers[4], 4, D + 4, 0, KT0, true);              // fusion.0, second pass (same weights: the sums add up)
+        add_job(fwd.layers[1], 1, D + 1, 0, 8, true);                // fusion.2, first pass
+        add_job(fwd.layers[5], 5, D + 5, 0, 8, true);                // fusion.2, second pass
+        add_job(fwd.layers[2], 2, D + 2, 0, 8, true);                // attention.0
+        add_job(fwd.layers[3], 3, D + 3, 0, 2, true);                // attention.2
+        add_job(fwd.layers[6], 6, D + 6, 0, 8, true);                // output_proj
+        for (int l = 0; l < n; ++l) add_job(fwd.layers[7 + l], 7 + l, D + 7 + l, 0, 8, true);
+        add_job(fwd.layers[7 + n], 7 + n, D + 7 + n, 0, 8, true);    // density_head
+        add_job(fwd.layers[8 + n], 7 + n, D + 8 + n, 0, 8, true);    // feature_head
+        add_job(fwd.layers[9 + n], 8 + n, D + 9 + n, 0, 8, true);    // color_layers.0, feature columns
+        add_job(fwd.layers[9 + n], 8 + n, D + 9 + n, 8, 1, false);   // color_layers.0, direction columns
+        add_job(fwd.layers[10 + n], 9 + n, D + 10 + n, 0, 4, true);  // color_layers.2
+        add_job(fwd.layers[11 + n], 10 + n, D + 11 + n, 0, 2, true); // color_layers.4
         return true;
     }
     tp.slot_tiles.assign(2 * n + 9, 8);

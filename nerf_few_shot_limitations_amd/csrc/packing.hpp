@@ -67,6 +67,7 @@ struct GradJobPlan {
 struct TrainPlan {
     std::vector<int> slot_tiles;                 // feature tiles (of 32) per saved-tensor slot
     int n_mask_slots = 0;                        // ReLU-mask bit planes, one per layer followed by a ReLU (except the heads)
+    int aux_floats = 0;                          // extra fp32 values saved per sample (V3: the softmax gate)
     std::vector<GradJobPlan> jobs;
 };
 bool make_train_plan(const nrf_arch& arch, const NetPlan& fwd, const ParamLayout& lay, TrainPlan& tp, std::string& err);

@@ -24,6 +24,7 @@ struct TrainKArgs {
     const float* x_enc;       // V1: (P, pe_dim)
     const float* pos;         // V2: (P,3)
     const float* dir;         // V2: (P,3)
+    const float* dino;        // V3: (P, dino_dim) per-sample features
     int64_t n;                // samples
     int64_t n_tiles;          // workgroup tiles of WAVES*32 samples
     float* out4;              // V1 forward: (P,4) written; backward: the same tensor, read (sigmoid')
@@ -36,6 +37,7 @@ struct TrainKArgs {
     int64_t slot_off[kMaxSlots];
     int slot_tiles[kMaxSlots];
     int64_t mask_off[kMaxMaskSlots];   // ReLU-mask bit planes: kMaskBytes per sample tile each
+    int64_t aux_off;                   // V3: (padded samples, 2) fp32 softmax gate
 };
 
 // ---- host-side helpers shared by train_v1.hip / train_v2.hip -------------------------------------------------
@@ -59,12 +61,13 @@ inline bool fill_slots(const TrainDev& t, int mode, int64_t n, TrainKArgs& k, st
         k.mask_off[i] = off;
         off += nt * kFragBytes;
     }
+    k.aux_off = off;
     return true;
 }
 
 inline bool check_train_common(const DeviceNet& net, const TrainDev& t, int mode, std::string& err) {
     if (mode < 0 || mode > 2) { err = "unknown mma_mode"; return false; }
-    if (net.arch.pos_freq != 10) { err = "the training path is built for pos_freq 10"; return false; }
+    if (net.arch.pos_freq != (net.arch.net == NRF_NET_V3 ? 12 : 10)) { err = "the training path is built for pos_freq 10 (V1, V2) and 12 (V3)"; return false; }
     if (!t.bstream[mode] || !t.maps) { err = "model not prepared for training"; return false; }
     if (net.n_bias > kBiasMaxFloats) { err = "bias table exceeds the LDS carve-out"; return false; }
     return true;

@@ -135,7 +135,7 @@ bool check_train(const DeviceNet& net, const TrainDev& t, int mode, std::string&
 int64_t train_ctx_bytes(const TrainDev& t, int mode, int64_t n) {
     int64_t tiles = 0;
     for (int i = 0; i < t.n_slots; ++i) tiles += t.slot_tiles[i];
-    return tiles32(n) * (tiles * tile_bytes_of(mode) + (int64_t)t.n_mask_slots * kFragBytes);
+    return tiles32(n) * (tiles * tile_bytes_of(mode) + (int64_t)t.n_mask_slots * kFragBytes + 32 * (int64_t)t.aux_floats * 4);
 }
 
 int launch_train_forward(const DeviceNet& net, const TrainDev& t, int mode, const float* x_enc, int64_t n, float* out4, void* ctx,

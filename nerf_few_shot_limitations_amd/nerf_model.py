@@ -210,12 +210,10 @@ class NeRFMLP(nn.Module):
 
     def forward(self, positions, directions=None, dino_features=None):
         if self._wants_grad():
-            if self.net == L.NRF_NET_V3:
-                raise NotImplementedError("the backward of the HIP path is built for the legacy NeRFMLP(pos_dim=63) form and for the "
-                                          "trainer form with use_dino=False (SURVEY.md section 8 f1); call a use_dino=True model under "
-                                          "torch.no_grad().")
             from .training import mlp_v1_train, mlp_v2_train
-            return mlp_v1_train(self, positions) if self.net == L.NRF_NET_V1 else mlp_v2_train(self, positions, directions)
+            if self.net == L.NRF_NET_V1:
+                return mlp_v1_train(self, positions)
+            return mlp_v2_train(self, positions, directions, dino_features)
         mode = L.MMA_MODES[self.mma_mode]
         x = L.dev_f32(positions)
         h = self.handle(x.device)

@@ -146,10 +146,10 @@ class _MLPV1Fn(torch.autograd.Function):
 
 
 class _MLPV2Fn(torch.autograd.Function):
-    """nerf_mlp.py:134-158 without the DINO branch: (positions, directions) -> (rgb, density)."""
+    """nerf_mlp.py:134-158: (positions, directions[, dino features]) -> (rgb, density); V2 and V3 models."""
 
     @staticmethod
-    def forward(ctx, module, pos, dirs, *params):
+    def forward(ctx, module, pos, dirs, dino, *params):
         dev = pos.device
         h, mode = _train_handle(module, dev)
         n = pos.shape[0]
@@ -160,8 +160,8 @@ class _MLPV2Fn(torch.autograd.Function):
             if nbytes < 0:
                 raise L.NrfError(-2, L.lib().nrf_last_error().decode("utf-8", "replace"))
             buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
-            L.check(L.lib().nrf_mlp_forward_train(h, mode, L.ptr(pos), L.ptr(dirs), n, L.ptr(rgb), L.ptr(dens), C.c_void_p(buf.data_ptr()), nbytes,
-                                                  L.stream_ptr()))
+            L.check(L.lib().nrf_mlp_forward_train(h, mode, L.ptr(pos), L.ptr(dirs), L.ptr(dino), n, L.ptr(rgb), L.ptr(dens),
+                                                  C.c_void_p(buf.data_ptr()), nbytes, L.stream_ptr()))
         ctx.module, ctx.buf, ctx.nbytes, ctx.n, ctx.mode = module, buf, nbytes, n, mode
         ctx.versions = module._versions()
         ctx.save_for_backward(rgb, dens)
@@ -185,16 +185,25 @@ class _MLPV2Fn(torch.autograd.Function):
                                              C.c_void_p(ctx.buf.data_ptr()), ctx.nbytes, L.ptr(grad), L.stream_ptr()))
         ctx.buf = None
         if direct is not None:
-            return (None, None, None) + (None,) * len(fp.offsets)
-        return (None, None, None, *fp.views(grad))
+            return (None, None, None, None) + (None,) * len(fp.offsets)
+        return (None, None, None, None, *fp.views(grad))
 
 
-def mlp_v2_train(module, positions, directions):
-    """(P,3) positions, (P,3) directions -> rgb (P,3), density (P,1), differentiable with respect to the parameters."""
+def mlp_v2_train(module, positions, directions, dino_features=None):
+    """(P,3) positions, (P,3) directions [, (P,C) DINO features for the use_dino=True form] -> rgb (P,3), density (P,1),
+    differentiable with respect to the parameters (not the inputs: a feature tensor that requires grad is refused)."""
     pos = L.dev_f32(positions).reshape(-1, 3)
     dirs = L.dev_f32(directions, pos.device).reshape(-1, 3)
+    dino = None
+    if module.net == L.NRF_NET_V3:
+        if dino_features is None:
+            raise ValueError("use_dino=True needs dino_features")
+        if getattr(dino_features, "requires_grad", False):
+            raise NotImplementedError("no gradient with respect to the DINO features is produced (the feature extractor, LoRA "
+                                      "included, is outside the HIP path: SURVEY.md section 8 f4); detach them")
+        dino = L.dev_f32(dino_features, pos.device).reshape(-1, module.dino_dim)
     module.flat_params().ensure()
-    return _MLPV2Fn.apply(module, pos, dirs, *module.flat_params().params())
+    return _MLPV2Fn.apply(module, pos, dirs, dino, *module.flat_params().params())
 
 
 def mlp_v1_train(module, x_enc):
@@ -364,6 +373,7 @@ class FusedStep:
         step = FusedStep(model, lr=5e-4, weight_decay=1e-6)
         loss = step(points, z_vals, rays_d, target)               # V1: points = encoded (R*S, 63)
         loss = step(points, z_vals, rays_d, target, dirs=dirs)    # V2: points (R*S, 3), dirs (R*S, 3)
+        loss = step(points, z_vals, rays_d, target, dirs=dirs, dino=feats)    # V3: + per-sample DINO features (R*S, C)
     """
 
     def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, rgb_weight=1.0, white_bkgd=False,
@@ -371,8 +381,8 @@ class FusedStep:
         """data_parallel=True (inside an initialised torch.distributed job): every rank passes ITS shard of the ray batch
         (equal sizes), the flat gradient vector is averaged over the ranks with one all-reduce before Adam, and the
         returned loss is this rank's."""
-        if model.net not in (L.NRF_NET_V1, L.NRF_NET_V2):
-            raise NotImplementedError("FusedStep: V1 and V2 models only")
+        if model.net not in (L.NRF_NET_V1, L.NRF_NET_V2, L.NRF_NET_V3):
+            raise NotImplementedError("FusedStep: unknown network family")
         self.model = model
         self.data_parallel = bool(data_parallel)
         self.group = process_group
@@ -396,7 +406,7 @@ class FusedStep:
             self._key = key
 
     @torch.no_grad()
-    def __call__(self, points, z_vals, rays_d, target, dirs=None):
+    def __call__(self, points, z_vals, rays_d, target, dirs=None, dino=None):
         m = self.model
         pts = L.dev_f32(points)
         dev = pts.device
@@ -404,7 +414,7 @@ class FusedStep:
         R, S = z.shape
         d = L.dev_f32(rays_d, dev).reshape(R, 3)
         tgt = L.dev_f32(target, dev).reshape(R, 3)
-        v2 = m.net == L.NRF_NET_V2
+        v2 = m.net != L.NRF_NET_V1                                   # trainer forms: positions + directions (+ DINO features)
         pts = pts.reshape(R * S, 3 if v2 else 3 * (2 * m.pos_freq + 1))
         n = R * S
         lib = L.lib()
@@ -419,7 +429,8 @@ class FusedStep:
                 rgb, den = o4.view(-1)[:3 * n].view(n, 3), o4.view(-1)[3 * n:].view(n, 1)
                 g_rgb, g_den = d4.view(-1)[:3 * n].view(n, 3), d4.view(-1)[3 * n:].view(n, 1)
                 dirs_d = L.dev_f32(dirs, dev).reshape(n, 3)
-                L.check(lib.nrf_mlp_forward_train(h, mode, L.ptr(pts), L.ptr(dirs_d), n, L.ptr(rgb), L.ptr(den), ctx, self.nbytes, st))
+                dino_d = L.dev_f32(dino, dev).reshape(n, m.dino_dim) if m.net == L.NRF_NET_V3 else None
+                L.check(lib.nrf_mlp_forward_train(h, mode, L.ptr(pts), L.ptr(dirs_d), L.ptr(dino_d), n, L.ptr(rgb), L.ptr(den), ctx, self.nbytes, st))
                 L.check(lib.nrf_composite(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(self.pred), None, None, st))
             else:
                 L.check(lib.nrf_mlp_forward_train_v1(h, mode, L.ptr(pts), n, L.ptr(o4), ctx, self.nbytes, st))

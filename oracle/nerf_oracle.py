@@ -537,9 +537,9 @@ def mlp_v1_train_emulated(p: Dict[str, torch.Tensor], x_enc: torch.Tensor, g_out
     return out, grads, h, dzs[::-1] + [d_head]
 
 
-def relu_margin(p: Dict[str, torch.Tensor], variant: str, x, directions=None) -> torch.Tensor:
-    """Per sample, the smallest |pre-activation| over every ReLU of the network ('v1': x = encoded points; 'v2':
-    x = positions).  A sample whose margin is within summation-order noise of 0 has an ill-defined ReLU mask: its
+def relu_margin(p: Dict[str, torch.Tensor], variant: str, x, directions=None, dino=None) -> torch.Tensor:
+    """Per sample, the smallest |pre-activation| over every ReLU of the network ('v1': x = encoded points; 'v2' / 'v3':
+    x = positions; 'v3' also takes the per-sample DINO features).  A sample whose margin is within summation-order noise of 0 has an ill-defined ReLU mask: its
     gradient legitimately differs between any two correct implementations (tests exclude such samples)."""
     def stack(prefix, h, step):
         m = torch.full((h.shape[0],), float("inf"))
@@ -552,8 +552,24 @@ def relu_margin(p: Dict[str, torch.Tensor], variant: str, x, directions=None) ->
         return h, m
     if variant == "v1":
         return stack("layers.", x, 1)[1]
-    pe = positional_encoding(x, 10)
-    h, m = stack("density_mlp.density_layers.", pe, 2)
+    if variant == "v3":                                            # lora_dino.py:171-193: every ReLU of both fusion passes and the gate
+        pe = positional_encoding(x, 12)
+        m0 = torch.full((pe.shape[0],), float("inf"))
+
+        def fusion(inp, m):
+            z0 = _lin(p, "dino_fusion.fusion.0", inp)
+            z1 = _lin(p, "dino_fusion.fusion.2", F.relu(z0))
+            return F.relu(z1), torch.minimum(m, torch.minimum(z0.abs().amin(-1), z1.abs().amin(-1)))
+        fused, m0 = fusion(torch.cat([pe, dino], -1), m0)
+        za = _lin(p, "dino_fusion.attention.0", fused)
+        m0 = torch.minimum(m0, za.abs().amin(-1))
+        w = torch.softmax(_lin(p, "dino_fusion.attention.2", F.relu(za)), -1)
+        final, m0 = fusion(torch.cat([pe * w[:, 0:1], dino * w[:, 1:2]], -1), m0)
+        h, m = stack("density_mlp.density_layers.", _lin(p, "dino_fusion.output_proj", final), 2)
+        m = torch.minimum(m, m0)
+    else:
+        pe = positional_encoding(x, 10)
+        h, m = stack("density_mlp.density_layers.", pe, 2)
     dens = _lin(p, "density_mlp.density_head", h)
     feat = _lin(p, "density_mlp.feature_head", h)
     m = torch.minimum(m, dens.abs().amin(-1))

@@ -247,10 +247,10 @@ def main():
     save("end_to_end", **e2e)
 
 
-def select_rays(margin_per_sample, R, S, need):
+def select_rays(margin_per_sample, R, S, need, margin=1e-4):
     """Indices of the first `need` rays all of whose samples keep every ReLU pre-activation away from 0 (oracle.relu_margin):
     for the others the ReLU mask -- hence the gradient -- is decided by summation order, in the reference as anywhere."""
-    ok = (margin_per_sample.reshape(R, S) > 1e-4).all(dim=1).nonzero().flatten()
+    ok = (margin_per_sample.reshape(R, S) > margin).all(dim=1).nonzero().flatten()
     assert ok.numel() >= need, (ok.numel(), need)
     return ok[:need]
 
@@ -307,6 +307,26 @@ def training():
         out["v2_grad_density_mlp." + k] = npf(thin(q.grad))
     for k, q in cm.named_parameters():
         out["v2_grad_color_mlp." + k] = npf(thin(q.grad))
+    # ---- V3: NeRFWithDINO(pos_freq=12, dino_dim=64, num_density_layers=3) -> VolumeRenderer -> mse (train.py:229-287, use_dino=True)
+    p3 = O.make_weights("v3", 2, "solid", n_layers=3)
+    dino_all = torch.from_numpy(O.uniform01(303, cand * S * 64).reshape(cand, S, 64) * 2 - 1).float()
+    keep = select_rays(O.relu_margin(p3, "v3", pts.reshape(-1, 3), dirs.reshape(-1, 3), dino_all.reshape(-1, 64)), cand, S, R, margin=4e-5)
+    m3 = ref_mlp.NeRFWithDINO(pos_freq=12, dir_freq=4, dino_dim=64, hidden_dim=256, num_density_layers=3)
+    sd = m3.state_dict()
+    for k in sd:
+        if k in p3:
+            sd[k] = p3[k]
+    m3.load_state_dict(sd)
+    with torch.enable_grad():
+        col, dn = m3(pts[keep].reshape(-1, 3), dirs[keep].reshape(-1, 3), dino_all[keep].reshape(-1, 64))
+        rgb_map, _, _ = vr(col.reshape(R, S, 3), dn.reshape(R, S, 1), z[keep], rd[keep])
+        loss = torch.nn.functional.mse_loss(rgb_map, tgt_all[keep])
+        loss.backward()
+    out.update(v3_pts=npf(pts[keep]), v3_dirs=npf(dirs[keep]), v3_dino=npf(dino_all[keep]), v3_z=npf(z[keep]), v3_rays_d=npf(rd[keep]),
+               v3_target=npf(tgt_all[keep]), v3_pred=npf(rgb_map), v3_loss=np.float32(loss.item()))
+    for k, q in m3.named_parameters():
+        if k in p3:
+            out["v3_grad_" + k] = npf(thin(q.grad))
     save("train_grads", **out)
 
 

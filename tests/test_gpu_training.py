@@ -447,10 +447,67 @@ def test_fused_adam_loop_reduces_loss(N):
     assert losses[-1] < 0.7 * losses[0], losses
 
 
-def test_forward_with_grad_refuses_the_dino_form(N):
+def test_dino_features_that_require_grad_are_refused(N):
+    """The DINO extractor (LoRA included) is outside the HIP path: no gradient flows to the features, and saying so
+    beats silently dropping it."""
     m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64).cuda().train()
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 64).cuda())
+        m(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 64).cuda().requires_grad_(True))
+
+
+# ---------------------------------------------------------------------------------------------
+# V3: NeRFWithDINO (train.py with use_dino=True): fusion block twice on the same weights, softmax gate
+# ---------------------------------------------------------------------------------------------
+def make_v3(N, mode, scene="fog", n_layers=8, dino_dim=64, seed=2):
+    m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=n_layers, use_dino=True, dino_dim=dino_dim, mma_mode=mode)
+    p = O.make_weights("v3", seed, scene, n_layers=n_layers, dino_dim=dino_dim)
+    m.load_state_dict(p, strict=False)
+    return m.cuda().train(), p
+
+
+def v3_inputs(n, dino_dim=64, seed=25):
+    pos, dirs, g_rgb, g_den = v2_inputs(n, seed)
+    dino = torch.from_numpy(O.uniform01(seed + 9, n * dino_dim).reshape(n, dino_dim) * 2 - 1).float()
+    return pos, dirs, dino, g_rgb, g_den
+
+
+@pytest.mark.parametrize("n,n_layers,dino_dim", [(1000, 8, 64), (300, 8, 128), (4096 + 17, 8, 64), (500, 3, 64), (500, 2, 64)])
+def test_v3_gradients_fp32_mode_match_autograd(N, n, n_layers, dino_dim):
+    model, p = make_v3(N, "f32", scene="solid", n_layers=n_layers, dino_dim=dino_dim)
+    pos, dirs, dino, g_rgb, g_den = v3_inputs(n, dino_dim)
+    keep = (O.relu_margin(p, "v3", pos, dirs, dino) > MARGIN)[:, None]
+    assert keep.float().mean() > 0.85
+    g_rgb, g_den = g_rgb * keep, g_den * keep
+    rgb, den = model(pos.cuda(), dirs.cuda(), dino.cuda())
+    ((rgb * g_rgb.cuda()).sum() + (den * g_den.cuda()).sum()).backward()
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    o_rgb, o_den = O.mlp_v3(pp, pos, dirs, dino)
+    assert (rgb.detach().cpu() - o_rgb.detach()).abs().max() < 1e-4 and rel_to_max(den, o_den) < 1e-4
+    ((o_rgb * g_rgb).sum() + (o_den * g_den).sum()).backward()
+    checked = 0
+    for name, q in model.named_parameters():
+        if name in pp:
+            assert rel_to_max(q.grad, pp[name].grad) < 2e-4, (name, rel_to_max(q.grad, pp[name].grad))
+            checked += 1
+    assert checked == 2 * (n_layers + 10)
+
+
+@pytest.mark.parametrize("mode,cos_min", [("bf16", 0.95), ("f16", 0.99)])
+def test_v3_gradients_16bit_modes_vs_fp32_autograd(N, mode, cos_min):
+    n = 3000
+    model, p = make_v3(N, mode)
+    pos, dirs, dino, g_rgb, g_den = v3_inputs(n, 64, seed=35)
+    rgb, den = model(pos.cuda(), dirs.cuda(), dino.cuda())
+    ((rgb * g_rgb.cuda()).sum() + (den * g_den.cuda()).sum()).backward()
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    o_rgb, o_den = O.mlp_v3(pp, pos, dirs, dino)
+    ((o_rgb * g_rgb).sum() + (o_den * g_den).sum()).backward()
+    for name, q in model.named_parameters():
+        # density_head's gradient is gated by relu'(density): on this scene the densities hover around 0 and their sign, after
+        # a 16-bit forward through the fusion block twice and the trunk, is rounding noise -- a 256-element vector built from
+        # that gate is not a meaningful direction test
+        if name in pp and name.endswith("weight") and "density_head" not in name:
+            assert cosine(q.grad, pp[name].grad) > cos_min, (name, cosine(q.grad, pp[name].grad))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -588,10 +645,30 @@ def test_v2_backward_matches_reference_golden(N, golden):
         assert np.abs(thin(q.grad).cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), name
 
 
+def test_v3_backward_matches_reference_golden(N, golden):
+    g = golden("train_grads")
+    R, S = g["v3_z"].shape
+    model, _ = make_v3(N, "f32", scene="solid", n_layers=3)
+    rgb, den = model(torch.from_numpy(g["v3_pts"]).reshape(-1, 3).cuda(), torch.from_numpy(g["v3_dirs"]).reshape(-1, 3).cuda(),
+                     torch.from_numpy(g["v3_dino"]).reshape(-1, 64).cuda())
+    rgb_map = N.VolumeRenderer()(rgb.reshape(R, S, 3), den.reshape(R, S, 1), torch.from_numpy(g["v3_z"]).cuda(),
+                                 torch.from_numpy(g["v3_rays_d"]).cuda())[0]
+    loss = torch.nn.functional.mse_loss(rgb_map, torch.from_numpy(g["v3_target"]).cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g["v3_loss"])) < 1e-5 * float(g["v3_loss"]) + 1e-7
+    checked = 0
+    for name, q in model.named_parameters():
+        if "v3_grad_" + name in g:
+            ref = g["v3_grad_" + name]
+            assert np.abs(thin(q.grad).cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), name
+            checked += 1
+    assert checked == 26
+
+
 # ---------------------------------------------------------------------------------------------
 # FusedStep: the same step without autograd in between
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("net,mode", [("v1", "f32"), ("v1", "bf16"), ("v2", "f32"), ("v2", "bf16")])
+@pytest.mark.parametrize("net,mode", [("v1", "f32"), ("v1", "bf16"), ("v2", "f32"), ("v2", "bf16"), ("v3", "f32"), ("v3", "bf16")])
 def test_fused_step_equals_autograd_route(N, net, mode):
     from nerf_few_shot_limitations_amd.training import Adam, FusedStep
     R, S, steps = 160, 32, 4
@@ -604,10 +681,15 @@ def test_fused_step_equals_autograd_route(N, net, mode):
         a, _ = make_model(N, mode, scene="solid")
         b, _ = make_model(N, mode, scene="solid")
         pts = O.positional_encoding(pos, 10).cuda()
-    else:
+    elif net == "v2":
         a, _ = make_v2(N, mode, scene="solid")
         b, _ = make_v2(N, mode, scene="solid")
         pts = pos.cuda()
+    else:
+        a, _ = make_v3(N, mode, scene="solid")
+        b, _ = make_v3(N, mode, scene="solid")
+        pts = pos.cuda()
+    dino = torch.from_numpy(O.uniform01(105, R * S * 64).reshape(R * S, 64) * 2 - 1).float().cuda() if net == "v3" else None
     opt = Adam(a, lr=5e-4, weight_decay=1e-6)
     vr = N.VolumeRenderer()
     ref_losses = []
@@ -616,14 +698,14 @@ def test_fused_step_equals_autograd_route(N, net, mode):
         if net == "v1":
             pred = N.volume_render_radiance(a(pts).view(R, 1, S, 4), z.view(R, 1, S), rd.view(R, 1, 3)).view(R, 3)
         else:
-            c, sg = a(pts, dirs, None)
+            c, sg = a(pts, dirs, dino)
             pred = vr(c.view(R, S, 3), sg.view(R, S, 1), z, rd)[0]
         loss = torch.nn.functional.mse_loss(pred, tgt)
         loss.backward()
         opt.step()
         ref_losses.append(loss.item())
     step = FusedStep(b, lr=5e-4, weight_decay=1e-6)
-    got = [step(pts, z, rd, tgt, dirs=dirs if net == "v2" else None).item() for _ in range(steps)]
+    got = [step(pts, z, rd, tgt, dirs=dirs if net != "v1" else None, dino=dino).item() for _ in range(steps)]
     # same kernels on both routes; only the fp32 atomics of the weight gradients are order dependent, and Adam's first
     # steps turn gradient noise around 0 into +-lr -- the 16-bit modes then see different operand roundings
     assert np.allclose(ref_losses, got, rtol=1e-5 if mode == "f32" else 2e-3, atol=1e-7), (ref_losses, got)

@@ -256,6 +256,26 @@ def test_training_gradients_v2_match_reference_backward(golden):
         assert np.abs(thin(v.grad).numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), k
 
 
+def test_training_gradients_v3_match_reference_backward(golden):
+    """NeRFWithDINO (fusion block twice on the same weights, softmax gate) + VolumeRenderer + mse."""
+    g = golden("train_grads")
+    R, S = g["v3_z"].shape
+    p = O.make_weights("v3", 2, "solid", n_layers=3)
+    pp = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    rgb, den = O.mlp_v3(pp, torch.from_numpy(g["v3_pts"]).reshape(-1, 3), torch.from_numpy(g["v3_dirs"]).reshape(-1, 3),
+                        torch.from_numpy(g["v3_dino"]).reshape(-1, 64))
+    rgb_map = O.volume_render(rgb.reshape(R, S, 3), den.reshape(R, S, 1), torch.from_numpy(g["v3_z"]), torch.from_numpy(g["v3_rays_d"]))[0]
+    loss = torch.nn.functional.mse_loss(rgb_map, torch.from_numpy(g["v3_target"]))
+    loss.backward()
+    assert abs(loss.item() - float(g["v3_loss"])) < 1e-6
+    n = 0
+    for k, v in pp.items():
+        ref = g["v3_grad_" + k]
+        assert np.abs(thin(v.grad).numpy() - ref).max() <= 1e-5 * np.abs(ref).max(), k
+        n += 1
+    assert n == 2 * (3 + 10)
+
+
 def test_emulated_training_arithmetic_is_autograd_in_fp32():
     """The rounding-aware restatement used to check the 16-bit kernels is, without rounding, exactly autograd."""
     p = O.make_weights("v1", 0, "solid")

@@ -244,6 +244,7 @@ def test_training_entry_points_validate_arguments(L):
     assert lib.nrf_model_update_device(None, None, 1, None) == -1 and b"null" in lib.nrf_last_error()
     assert lib.nrf_mlp_forward_train_v1(None, 0, None, 4, None, None, 0, None) == -1
     assert lib.nrf_mlp_backward(None, 0, None, None, None, None, 4, None, 0, None, None) == -1
+    assert lib.nrf_mlp_forward_train(None, 0, None, None, None, 4, None, None, None, 0, None) == -1
     assert lib.nrf_adam_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == -1
     assert lib.nrf_adam_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, None) == -1      # steps count from 1
     assert lib.nrf_adam_step(None, None, None, None, 0, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == 0       # nothing to do
@@ -259,4 +260,12 @@ def test_training_entry_points_validate_arguments(L):
         arr[i] = L.nrf_linear(w.ctypes.data_as(L.c_float_p), b.ctypes.data_as(L.c_float_p), w.shape[0], w.shape[1])
     arch = L.nrf_arch(3, 12, 4, 256, 8, 64)
     n = C.c_int64()
-    assert lib.nrf_debug_train_plan(C.byref(arch), arr, len(names), None, 0, C.byref(n)) == -2           # no backward for the DINO form
+    assert lib.nrf_debug_train_plan(C.byref(arch), arr, len(names), None, 0, C.byref(n)) == 0
+    buf = np.zeros(n.value, np.int32)
+    assert lib.nrf_debug_train_plan(C.byref(arch), arr, len(names), buf.ctypes.data_as(C.c_void_p), n.value, None) == 0
+    n_slots = int(buf[0])
+    assert n_slots == 23 + 2 * 8 and list(buf[1:1 + n_slots][[0, 3, 4]]) == [5, 2, 5]        # [pe(3)|dino(2)] tiles, attention.0, scaled inputs
+    assert int(buf[1 + n_slots]) == 8 + 13                                                  # jobs: both fusion layers twice
+    assert int(buf[-1]) == 7 + 8                                                            # ReLU bit planes
+    arch_bad = L.nrf_arch(7, 12, 4, 256, 8, 64)
+    assert lib.nrf_debug_train_plan(C.byref(arch_bad), arr, len(names), None, 0, C.byref(n)) < 0

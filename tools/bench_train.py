@@ -39,7 +39,7 @@ def timed(fn, steps, warmup=3):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
-    ap.add_argument("--net", default="v1", choices=["v1", "v2"])
+    ap.add_argument("--net", default="v1", choices=["v1", "v2", "v3"])
     ap.add_argument("--samples", type=int, nargs="+", default=[65536, 1048576])
     ap.add_argument("--rays-samples", type=int, default=32, help="samples per ray of the whole-step timing")
     ap.add_argument("--steps", type=int, default=20)
@@ -47,18 +47,24 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    v2 = args.net == "v2"
-    if v2:
+    v2 = args.net != "v1"
+    v3 = args.net == "v3"
+    if v3:
+        model = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=args.mode).to(dev).train()
+    elif v2:
         model = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=args.mode).to(dev).train()
     else:
         model = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=args.mode).to(dev).train()
     fwd_flops = model.flops_per_sample()
     first_dx = 2 * 63 * 256 + (2 * 27 * 128 if v2 else 0)          # no gradient with respect to the encoded inputs
+    if v3:
+        first_dx = 2 * 139 * 256 + 2 * 27 * 128                    # first fusion pass only; the second pass needs d inputs for the gate
     bwd_flops = 2 * fwd_flops - first_dx
     out_lines = []
     for n in args.samples:
         x = torch.rand(n, 3 if v2 else 63, device=dev) * 2 - 1
         dirs = torch.rand(n, 3, device=dev) * 2 - 1
+        dino = torch.rand(n, 64, device=dev) * 2 - 1 if v3 else None
         g = torch.rand(n, 4, device=dev) - 0.5
         g3, g1 = g[:, :3].contiguous(), g[:, 3:].contiguous()
         h, mode = _train_handle(model, dev)
@@ -71,7 +77,7 @@ def main():
 
         def fwd():
             if v2:
-                L.check(L.lib().nrf_mlp_forward_train(h, mode, L.ptr(x), L.ptr(dirs), n, L.ptr(rgb), L.ptr(den), ctx, nbytes, L.stream_ptr()))
+                L.check(L.lib().nrf_mlp_forward_train(h, mode, L.ptr(x), L.ptr(dirs), L.ptr(dino), n, L.ptr(rgb), L.ptr(den), ctx, nbytes, L.stream_ptr()))
             else:
                 L.check(L.lib().nrf_mlp_forward_train_v1(h, mode, L.ptr(x), n, L.ptr(out), ctx, nbytes, L.stream_ptr()))
 
@@ -90,13 +96,14 @@ def main():
         d = torch.rand(R, 3, device=dev) - 0.5
         tgt = torch.rand(R, 3, device=dev)
         xs, ds = x[:R * S], dirs[:R * S]
+        dn = dino[:R * S] if v3 else None
         opt = Adam(model, lr=5e-4)
         vr = N.VolumeRenderer()
 
         def step():
             opt.zero_grad()
             if v2:      # train.py:229-236
-                c, sg = model(xs, ds, None)
+                c, sg = model(xs, ds, dn)
                 pred = vr(c.view(R, S, 3), sg.view(R, S, 1), z, d)[0]
             else:       # train_minimal.py:102-120
                 pred = N.volume_render_radiance(model(xs).view(R, 1, S, 4), z.view(R, 1, S), d.view(R, 1, 3)).view(R, 3)
@@ -111,10 +118,10 @@ def main():
         t_wall = (time.perf_counter() - t0) * 1e3 / args.steps
         fused = FusedStep(model, lr=5e-4)
         zs = z.contiguous()
-        t_fs = timed(lambda: fused(xs, zs, d, tgt, dirs=ds if v2 else None), args.steps)
+        t_fs = timed(lambda: fused(xs, zs, d, tgt, dirs=ds if v2 else None, dino=dn), args.steps)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            fused(xs, zs, d, tgt, dirs=ds if v2 else None)
+            fused(xs, zs, d, tgt, dirs=ds if v2 else None, dino=dn)
         torch.cuda.synchronize()
         t_fs_wall = (time.perf_counter() - t0) * 1e3 / args.steps
         line = {
@@ -138,7 +145,8 @@ def cpu_baseline(args):
     """The same optimisation step on the host cores with the CPU oracle + torch autograd + torch.optim.Adam (the
     reference's own arithmetic, train_minimal.py:97-123 / train.py:280-288), on a bounded batch."""
     from oracle import nerf_oracle as O
-    v2 = args.net == "v2"
+    v2 = args.net != "v1"
+    v3 = args.net == "v3"
     S = args.rays_samples
     R = max(args.cpu_samples // S, 1)
     threads = min(len(os.sched_getaffinity(0)), 16)
@@ -148,6 +156,7 @@ def cpu_baseline(args):
     opt = torch.optim.Adam(list(pp.values()), lr=5e-4)
     pos = torch.rand(R * S, 3) * 4 - 2
     dirs = torch.rand(R * S, 3) * 2 - 1
+    dino = torch.rand(R * S, 64) * 2 - 1
     z = torch.sort(torch.rand(R, S) * 4 + 2, dim=-1).values
     d = torch.rand(R, 3) - 0.5
     tgt = torch.rand(R, 3)
@@ -155,7 +164,10 @@ def cpu_baseline(args):
 
     def step():
         opt.zero_grad()
-        if v2:
+        if v3:
+            c, sg = O.mlp_v3(pp, pos, dirs, dino)
+            pred = O.volume_render(c.reshape(R, S, 3), sg.reshape(R, S, 1), z, d)[0]
+        elif v2:
             c, sg = O.mlp_v2(pp, pos, dirs)
             pred = O.volume_render(c.reshape(R, S, 3), sg.reshape(R, S, 1), z, d)[0]
         else:

@@ -8,9 +8,9 @@ Two constructor forms, as the reference uses them:
             (positions (P,3), directions (P,3), dino (P,C)|None) -> (rgb (P,3), density (P,1))
             src/training/train.py:82-89,229; the module tree mirrors
             src/models/nerf_mlp.py:86-158 (NeRFWithDINO) so checkpoints load by name.
-With grad enabled the legacy (V1) form and the trainer form without DINO (V2) run the training
-kernels (training.py: saved activations, transposed-stream backward, MFMA weight gradients); the
-DINO form (V3) is inference only and a grad-enabled call raises instead of silently detaching.
+With grad enabled every form runs the training kernels (training.py: saved activations,
+transposed-stream backward, MFMA weight gradients); gradients reach the parameters only -- a
+dino_features tensor that requires grad is refused instead of silently detached.
 """
 from __future__ import annotations
 

@@ -1,7 +1,7 @@
 """The training path: what `loss.backward()` / `optimizer.step()` of the reference's loops
 (src/training/train_minimal.py:80-127, src/training/train.py:244-292) run through on the GPU.
 
-  * `mlp_v1_train`   nerf_model.NeRFMLP.forward with grad enabled: libnerfhip's forward that saves
+  * `mlp_v1_train`, `mlp_v2_train`   NeRFMLP.forward with grad enabled: libnerfhip's forward that saves
                      every layer's operand tiles, and a backward made of the transposed weight-stream
                      chain + MFMA weight-gradient kernel (csrc/train_impl.hpp);
   * `composite`      nerf_mlp.VolumeRenderer / volume_render_radiance with grad enabled;

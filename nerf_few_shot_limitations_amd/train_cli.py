@@ -1,0 +1,191 @@
+"""python -m nerf_few_shot_limitations_amd.train_cli --config experiments/baseline.yaml --data data/nerf_synthetic/lego \\
+        [--epochs N] [--mode bf16|f16|f32] [--out DIR] [--dino-maps maps.pt] [--seed 0]
+
+The training run of `NeRFDINOTrainer` (src/training/train.py:244-292 `train_step`, :344-372 `train`) as a command on the
+HIP path: the YAML loads unchanged; per epoch and training view the rays are cast at the progressive schedule's
+resolution (focal scaled, target resized bilinearly: train.py:262-266), shuffled (:268) and consumed in ray batches
+(:270-288), each of them one `training.FusedStep` -- stratified samples -> NeRFMLP -> VolumeRenderer ->
+rgb_weight * mse -> backward -> Adam(lr, weight_decay) -- with MultiStepLR between epochs (:119-123), validation every
+`output.val_freq` epochs on the fused renderer (`evaluate_views`) and checkpoints under the reference's key names
+(:374-389, readable by evaluate.py:22-33 and by evaluate_cli).
+
+use_dino configs condition on the DINOv2 feature map of every training view (train.py:153-165), which cannot be produced
+offline: pass --dino-maps with a tensor (V,Hp,Wp,C) saved by torch.save, one map per training view; the features of a
+sample are fetched by projection into the view being trained on (:203-214) and carry no gradient.
+wandb, LPIPS and the DINO/LoRA optimiser are not part of this command.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import (evaluate_views, get_rays, load_blender_data, load_checkpoint_into, load_config, model_from_config, render_settings,
+               sample_points_along_rays)
+from .renderer import make_dino
+from .training import FusedStep
+
+
+def schedule_for(cfg, epoch):
+    """(H_train, W_train, N_samples, batch_size) of an epoch: train.py:249-259."""
+    t = cfg["training"]
+    s = t["progressive_schedule"]
+    if epoch < 50:
+        return (*s["epochs_0_50"], t["batch_size"] * 2)
+    if epoch < 100:
+        return (*s["epochs_50_100"], t["batch_size"])
+    return (*s["epochs_100_plus"], t["batch_size"] // 2)
+
+
+def lr_at(cfg, epoch):
+    """MultiStepLR(milestones, gamma) evaluated for the epoch about to run (train.py:119-123, scheduler.step() after each epoch)."""
+    o = cfg["optimizer"]
+    return float(o["lr"]) * float(o["lr_gamma"]) ** sum(1 for m in o["lr_milestones"] if epoch >= m)
+
+
+def view_rays(image, pose, H, W, focal, Ht, Wt):
+    """Rays and target of one training view at the schedule's resolution (train.py:174-186,262-266)."""
+    tgt = image
+    if tgt.shape[-1] == 4:
+        tgt = tgt[..., :3] * tgt[..., 3:4] + (1.0 - tgt[..., 3:4])
+    if (Ht, Wt) == (H, W):
+        ro, rd = get_rays(H, W, focal, pose)
+    else:
+        ro, rd = get_rays(Ht, Wt, focal * (Ht / H), pose)
+        tgt = F.interpolate(tgt.permute(2, 0, 1).unsqueeze(0), size=(Ht, Wt), mode="bilinear", align_corners=False).squeeze(0).permute(1, 2, 0)
+    return ro.reshape(-1, 3), rd.reshape(-1, 3), tgt.reshape(-1, 3).contiguous()
+
+
+def fetch_features(dino_struct, pts):
+    """(n,3) points -> (n,C) features of the source view (project_points_to_image + sample_features_at_points)."""
+    d, fm = dino_struct
+    n = pts.shape[0]
+    feats = torch.empty((n, int(fm.shape[-1])), dtype=torch.float32, device=pts.device)
+    L.check(L.lib().nrf_project_fetch(C.byref(d), L.ptr(pts), n, L.ptr(feats), None, L.stream_ptr()))
+    return feats
+
+
+def train_epoch(step, cfg, epoch, images, poses, H, W, focal, near, far, gen, dino_maps=None, max_batches=None):
+    """One pass of train.py:261-290 over the training views; returns (mean loss, ray-samples processed)."""
+    Ht, Wt, S, batch = schedule_for(cfg, epoch)
+    model = step.model
+    use_dino = model.net == L.NRF_NET_V3
+    total, n_batches, samples = None, 0, 0
+    for v in range(len(images)):
+        ro, rd, tgt = view_rays(images[v], poses[v], H, W, focal, Ht, Wt)
+        dino = make_dino(dino_maps[v:v + 1], poses[v], focal, H, W) if use_dino else None       # train.py:204-206: full-resolution intrinsics
+        order = torch.randperm(ro.shape[0], device=ro.device, generator=gen)
+        for i in range(0, order.shape[0], batch):
+            idx = order[i:i + batch]
+            o, d, t = ro[idx], rd[idx], tgt[idx]
+            pts, z = sample_points_along_rays(o, d, near, far, S, perturb=True, seed=epoch * 1_000_003 + v * 10_007 + i)
+            n = idx.shape[0]
+            dirs = d[:, None, :].expand(n, S, 3).reshape(-1, 3)                         # train.py:225: raw ray directions per sample
+            feats = fetch_features(dino, pts.reshape(-1, 3)) if use_dino else None
+            loss = step(pts.reshape(-1, 3), z, d, t, dirs=dirs, dino=feats)
+            total = loss if total is None else total + loss
+            n_batches += 1
+            samples += n * S
+            if max_batches is not None and n_batches >= max_batches:
+                return float(total) / n_batches, samples
+    return (float(total) / max(n_batches, 1)) if total is not None else 0.0, samples
+
+
+def save_checkpoint(path, model, step, epoch, best_psnr, cfg):
+    """train.py:374-389's dictionary: `nerf_model_state_dict` is what evaluate.py:27 / load_checkpoint_into read."""
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    opt = step.opt
+    torch.save({"epoch": epoch, "best_psnr": best_psnr,
+                "nerf_model_state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                "optimizer_state_dict": {"step": opt.step_count, "exp_avg": None if opt.exp_avg is None else opt.exp_avg.cpu(),
+                                         "exp_avg_sq": None if opt.exp_avg_sq is None else opt.exp_avg_sq.cpu(), "lr": opt.lr},
+                "config": cfg}, path)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("--config", required=True)
+    ap.add_argument("--data", required=True, help="dataset directory holding transforms_train.json / transforms_test.json")
+    ap.add_argument("--epochs", type=int, default=None, help="default: training.epochs of the config")
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--out", default=None, help="default: output.save_dir of the config")
+    ap.add_argument("--checkpoint", default=None, help="resume the model weights from this file")
+    ap.add_argument("--dino-maps", default=None)
+    ap.add_argument("--max-test-views", type=int, default=None)
+    ap.add_argument("--max-batches", type=int, default=None, help="stop every epoch after this many ray batches (smoke runs)")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+
+    torch.manual_seed(args.seed)                          # parameter init (when no checkpoint is given) and the ray shuffles
+    cfg = load_config(args.config)
+    rs = render_settings(cfg)
+    out_dir = args.out or cfg["output"]["save_dir"]
+    epochs = args.epochs if args.epochs is not None else int(cfg["training"]["epochs"])
+    name = cfg.get("experiment", {}).get("name", "run")
+    res = cfg["data"].get("resolution")
+    images, poses, (H, W, focal) = load_blender_data(args.data, "train", img_size=res)
+    nv = cfg["data"].get("num_views")
+    if nv:
+        images, poses = images[:nv], poses[:nv]                                          # train.py:141-143
+    dev = torch.device("cuda", torch.cuda.current_device())
+    images = [im.permute(1, 2, 0).float().to(dev) for im in images]
+    poses = [p.float() for p in poses]
+    test_images, test_poses, _ = load_blender_data(args.data, "test", img_size=res)
+    if args.max_test_views:
+        test_images, test_poses = test_images[: args.max_test_views], test_poses[: args.max_test_views]
+
+    use_dino = bool(cfg.get("model", {}).get("use_dino", True))
+    dino_maps, dino_dim = None, 64
+    if use_dino:
+        if not args.dino_maps:
+            raise SystemExit("this config conditions on DINO features: pass --dino-maps <tensor (V,Hp,Wp,C) saved with torch.save>, one map "
+                             "per training view")
+        dino_maps = torch.load(args.dino_maps, map_location="cpu", weights_only=True).float().to(dev)
+        if dino_maps.dim() != 4 or dino_maps.shape[0] < len(images):
+            raise SystemExit("--dino-maps must hold one (Hp,Wp,C) map per training view")
+        dino_dim = int(dino_maps.shape[-1])
+    model = model_from_config(cfg, dino_dim=dino_dim, mma_mode=args.mode)
+    if args.checkpoint:
+        load_checkpoint_into(model, torch.load(args.checkpoint, map_location="cpu", weights_only=True))
+    model = model.to(dev).train()
+    o, lw = cfg["optimizer"], cfg.get("loss", {})
+    step = FusedStep(model, lr=float(o["lr"]), weight_decay=float(o["weight_decay"]), rgb_weight=float(lw.get("rgb_weight", 1.0)),
+                     white_bkgd=rs["white_bkgd"])
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(args.seed)
+    best, log = 0.0, []
+    targets = test_images.permute(0, 2, 3, 1).contiguous()
+    eval_dino = dict(features=dino_maps[0:1], pose=poses[0], focal=focal, H=H, W=W) if use_dino else None      # train.py:203-208
+    for epoch in range(epochs):
+        step.opt.lr = lr_at(cfg, epoch)
+        t0 = time.perf_counter()
+        loss, samples = train_epoch(step, cfg, epoch, images, poses, H, W, focal, rs["near"], rs["far"], gen, dino_maps, args.max_batches)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rec = {"epoch": epoch + 1, "loss": loss, "lr": step.opt.lr, "seconds": round(dt, 3), "Msamples_per_s": round(samples / dt / 1e6, 2)}
+        if (epoch + 1) % int(cfg["output"]["val_freq"]) == 0 or epoch + 1 == epochs:
+            m = evaluate_views(model, test_poses, H, W, focal, rs["near"], rs["far"], rs["n_samples"], targets=targets, white_bkgd=rs["white_bkgd"],
+                               mma_mode=args.mode, dino=eval_dino, out_dir=os.path.join(out_dir, f"val_{epoch + 1}"))
+            model.train()
+            rec.update(psnr=m["psnr"], ssim=m["ssim"])
+            if m["psnr"] > best:
+                best = m["psnr"]
+                save_checkpoint(os.path.join(out_dir, f"best_{name}.pth"), model, step, epoch, best, cfg)
+        if (epoch + 1) % int(cfg["output"]["save_freq"]) == 0:
+            save_checkpoint(os.path.join(out_dir, f"epoch_{epoch + 1}.pth"), model, step, epoch, best, cfg)
+        log.append(rec)
+        print(json.dumps(rec), flush=True)
+    os.makedirs(out_dir, exist_ok=True)
+    with open(os.path.join(out_dir, "train_log.json"), "w") as f:
+        json.dump(log, f, indent=1)
+    return log
+
+
+if __name__ == "__main__":
+    main()

@@ -763,3 +763,78 @@ def test_data_parallel_two_ranks_equal_one_rank_on_the_whole_batch(N, route, tmp
     assert np.abs(got - ref).max() < bound, np.abs(got - ref).max()
     if route == "fused":
         assert np.mean(np.abs(got - ref) > 1e-4) < 0.02          # all but the elements whose gradient is noise around 0
+
+
+# ---------------------------------------------------------------------------------------------
+# the training run as a command (train.py:244-292,344-389 on the HIP path)
+# ---------------------------------------------------------------------------------------------
+def _write_scene(root, n_train=2, n_test=2, size=16):
+    import json, os
+    from PIL import Image
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32) / (size - 1)
+    for split, count in (("train", n_train), ("test", n_test)):
+        os.makedirs(os.path.join(root, split))
+        frames = []
+        for i in range(count):
+            # a smooth, bright target: with dark targets the quickest way down is density -> 0 everywhere, after which
+            # relu(density_head) passes no gradient at all (nerf_mlp.py:63) and the loss freezes
+            img = np.stack([0.6 + 0.4 * xx, 0.6 + 0.4 * yy, np.full_like(xx, 0.7 + 0.2 * i / max(count - 1, 1)), np.ones_like(xx)], -1)
+            Image.fromarray((img * 255).astype(np.uint8), "RGBA").save(os.path.join(root, split, f"r_{i}.png"))
+            pose = O.LEGO_LIKE_C2W.copy(); pose[0, 3] += 0.05 * i
+            frames.append({"file_path": f"./{split}/r_{i}", "transform_matrix": pose.tolist()})
+        json.dump({"camera_angle_x": O.CAMERA_ANGLE_X, "frames": frames}, open(os.path.join(root, f"transforms_{split}.json"), "w"))
+
+
+_CFG = ("experiment: {{name: tiny}}\ndata: {{near: 2.0, far: 6.0, resolution: 16, num_views: 2}}\n"
+        "rendering: {{near: 2.0, far: 6.0, chunk_size: 2048, white_bkgd: false}}\nmodel: {{use_dino: {dino}}}\n"
+        "nerf_model: {{pos_freq: {pf}, dir_freq: 4, hidden_dim: 256, num_layers: 8}}\n"
+        "training: {{epochs: 3, batch_size: 64, progressive_schedule: {{epochs_0_50: [16, 16, 8], epochs_50_100: [16, 16, 12], epochs_100_plus: [16, 16, 16]}}}}\n"
+        "optimizer: {{lr: 2.0e-3, weight_decay: 1.0e-6, lr_milestones: [2], lr_gamma: 0.5}}\nloss: {{rgb_weight: 1.0, depth_weight: 0.0, reg_weight: 0.0}}\n"
+        "output: {{save_dir: unused, val_freq: 2, save_freq: 3}}\n")
+
+
+@pytest.mark.parametrize("use_dino", [False, True])
+def test_train_cli_runs_the_reference_schedule(N, tmp_path, use_dino):
+    import json, os
+    from nerf_few_shot_limitations_amd import evaluate_cli, train_cli
+    root = str(tmp_path / "scene")
+    _write_scene(root)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(_CFG.format(dino="true" if use_dino else "false", pf=12 if use_dino else 10))
+    out = str(tmp_path / "run")
+    # start from the synthetic "fog" weights: torch's default init leaves every density at relu(~bias) and, when that bias
+    # happens to be negative, the whole network without gradient (the reference shares this trap: nerf_mlp.py:63)
+    p = dict(O.make_weights("v3" if use_dino else "v2", 2 if use_dino else 1, "fog"))
+    p["pos_encoder.freq_bands"] = 2.0 ** torch.linspace(0., 11 if use_dino else 9, 12 if use_dino else 10)
+    p["dir_encoder.freq_bands"] = 2.0 ** torch.linspace(0., 3, 4)
+    torch.save({"epoch": 0, "nerf_model_state_dict": p}, str(tmp_path / "init.pth"))
+    argv = ["--config", str(cfg), "--data", root, "--out", out, "--mode", "f32", "--epochs", "3", "--checkpoint", str(tmp_path / "init.pth")]
+    if use_dino:
+        maps = torch.from_numpy(O.uniform01(77, 2 * 4 * 4 * 64).reshape(2, 4, 4, 64) * 2 - 1).float()
+        torch.save(maps, str(tmp_path / "maps.pt"))
+        argv += ["--dino-maps", str(tmp_path / "maps.pt")]
+    log = train_cli.main(argv)
+    assert [r["epoch"] for r in log] == [1, 2, 3]
+    assert log[0]["lr"] == pytest.approx(2e-3) and log[2]["lr"] == pytest.approx(1e-3)           # MultiStepLR milestone at epoch 2
+    # 12 optimiser steps at a test-sized learning rate: the run must move (that it moves the right way is what the gradient
+    # and FusedStep tests establish; a dozen noisy steps from a synthetic init need not be monotone)
+    assert all(np.isfinite(r["loss"]) for r in log) and log[-1]["loss"] != log[0]["loss"]
+    assert "psnr" in log[1] and "psnr" in log[2] and np.isfinite(log[2]["psnr"])
+    files = sorted(os.listdir(out))
+    assert "best_tiny.pth" in files and "epoch_3.pth" in files and "train_log.json" in files and "val_2" in files
+    ck = torch.load(os.path.join(out, "best_tiny.pth"), map_location="cpu", weights_only=True)
+    assert "nerf_model_state_dict" in ck and "density_mlp.density_head.weight" in ck["nerf_model_state_dict"]
+    moved = max(float((ck["nerf_model_state_dict"][k] - p[k]).abs().max()) for k in p if k.endswith("weight"))
+    assert 1e-4 < moved < 0.1                                                                     # Adam at lr 2e-3 / 1e-3 for a handful of steps
+    if not use_dino:                                                                              # the checkpoint feeds the evaluation command
+        m = evaluate_cli.main(["--config", str(cfg), "--data", root, "--checkpoint", os.path.join(out, "best_tiny.pth"), "--mode", "f32"])
+        assert m["views"] == 2 and abs(m["psnr"] - max(r.get("psnr", 0) for r in log)) < 1e-3
+
+
+def test_train_cli_schedule_and_lr_rules():
+    from nerf_few_shot_limitations_amd import train_cli
+    cfg = {"training": {"batch_size": 1024, "progressive_schedule": {"epochs_0_50": [32, 32, 32], "epochs_50_100": [64, 64, 48], "epochs_100_plus": [128, 128, 64]}},
+           "optimizer": {"lr": 5e-4, "lr_milestones": [100, 150], "lr_gamma": 0.5}}
+    assert train_cli.schedule_for(cfg, 0) == (32, 32, 32, 2048) and train_cli.schedule_for(cfg, 49) == (32, 32, 32, 2048)      # train.py:249-259
+    assert train_cli.schedule_for(cfg, 50) == (64, 64, 48, 1024) and train_cli.schedule_for(cfg, 100) == (128, 128, 64, 512)
+    assert train_cli.lr_at(cfg, 99) == 5e-4 and train_cli.lr_at(cfg, 100) == 2.5e-4 and train_cli.lr_at(cfg, 150) == 1.25e-4

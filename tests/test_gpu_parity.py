@@ -277,14 +277,16 @@ def test_model_update_repacks(N, golden):
 
 
 def test_forward_under_grad_is_differentiable_or_refuses(N):
-    """V1/V2 run the training kernels under grad (tests/test_gpu_training.py); the DINO form has no backward and must
-    refuse instead of silently detaching; the fused renderer is inference only."""
+    """Every NeRFMLP form runs the training kernels under grad (tests/test_gpu_training.py); what has no backward -- the
+    DINO features' own gradient -- is refused instead of silently detached."""
     m, _ = model_v1(N)
     out = m(torch.zeros(4, 63).cuda())
     assert out.requires_grad and out.grad_fn is not None
     m3, _ = model_v3(N)
+    rgb, den = m3(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 64).cuda())
+    assert rgb.requires_grad and den.requires_grad
     with pytest.raises(NotImplementedError):
-        m3(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 64).cuda())
+        m3(torch.zeros(4, 3).cuda(), torch.zeros(4, 3).cuda(), torch.zeros(4, 64).cuda().requires_grad_(True))
 
 
 # ------------------------------------------------------------------ a11 fused renderer vs golden (reference outputs)

@@ -158,8 +158,10 @@ class NeRFMLP(nn.Module):
         ok = all(p.data_ptr() == base + 4 * off for p, off in zip(fp.params(), fp.offsets))
         return fp.flat if ok else None
 
-    def handle(self, device=None):
-        """The nrf_model* for this module on `device`, (re)packed if the parameters changed."""
+    def handle(self, device=None, mma_mode=None):
+        """The nrf_model* for this module on `device`, (re)packed if the parameters changed.  `mma_mode`: the arithmetic
+        mode the caller is about to run (default: the module's own) -- after a device-side re-pack only the modes that
+        were asked for hold the current parameters."""
         L.require_gpu()
         if device is None:
             p = next(self.parameters())
@@ -167,7 +169,7 @@ class NeRFMLP(nn.Module):
         device = torch.device(device)
         idx = device.index if device.index is not None else torch.cuda.current_device()
         ver = self._versions()
-        mode = L.MMA_MODES[self.mma_mode]
+        mode = L.MMA_MODES[mma_mode or self.mma_mode]
         same = self._handle is not None and self._handle_dev == idx
         if same and self._packed == ver and (self._packed_modes is None or mode in self._packed_modes):
             return self._handle

@@ -64,7 +64,7 @@ def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb
             raise ValueError("a use_dino model needs dino=dict(features=, pose=, focal=, H=, W=)")
         dn, keep = make_dino(**dino)
     opts = _opts(near, far, S, perturb, tr, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn, o.device, zin)
-    h = model.handle(o.device)
+    h = model.handle(o.device, mma_mode or model.mma_mode)
     with torch.cuda.device(o.device):
         rgb = torch.empty((R, 3), dtype=torch.float32, device=o.device)
         depth = torch.empty((R,), dtype=torch.float32, device=o.device)
@@ -100,7 +100,7 @@ def render_camera(model: NeRFMLP, H, W, focal, c2w, near, far, N_samples=64, ray
             raise ValueError("a use_dino model needs dino=...")
         dn, keep = make_dino(**dino)
     opts = _opts(near, far, N_samples, perturb, None, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode, dn, device)
-    h = model.handle(device)
+    h = model.handle(device, mma_mode or model.mma_mode)
     with torch.cuda.device(device):
         rgb = out_rgb if out_rgb is not None else torch.empty((n, 3), dtype=torch.float32, device=device)
         depth = out_depth if out_depth is not None else torch.empty((n,), dtype=torch.float32, device=device)

@@ -85,7 +85,8 @@ class TileJob:
         self._dn = self._keep = None
         if model.net == L.NRF_NET_V3:
             self._dn, self._keep = make_dino(**dino)
-        self.opts = _opts(near, far, N_samples, perturb, None, seed, lindisp, ert_eps, white_bkgd, mma_mode or model.mma_mode,
+        self.mma_mode = mma_mode or model.mma_mode
+        self.opts = _opts(near, far, N_samples, perturb, None, seed, lindisp, ert_eps, white_bkgd, self.mma_mode,
                           self._dn, self.device)
         self.model = model
         self.poses, self.V = _poses12(c2w)
@@ -100,7 +101,7 @@ class TileJob:
         return min(8, self.V) * self.n_real * self.tile_rays
 
     def launch(self):
-        h = self.model.handle(self.device)
+        h = self.model.handle(self.device, self.mma_mode)
         with torch.cuda.device(self.device):
             for v0 in range(0, self.V, 8):
                 nv = min(8, self.V - v0)

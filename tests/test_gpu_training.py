@@ -838,3 +838,38 @@ def test_train_cli_schedule_and_lr_rules():
     assert train_cli.schedule_for(cfg, 0) == (32, 32, 32, 2048) and train_cli.schedule_for(cfg, 49) == (32, 32, 32, 2048)      # train.py:249-259
     assert train_cli.schedule_for(cfg, 50) == (64, 64, 48, 1024) and train_cli.schedule_for(cfg, 100) == (128, 128, 64, 512)
     assert train_cli.lr_at(cfg, 99) == 5e-4 and train_cli.lr_at(cfg, 100) == 2.5e-4 and train_cli.lr_at(cfg, 150) == 1.25e-4
+
+
+def test_render_in_another_mode_after_training_sees_the_new_weights(N):
+    """The device-side re-pack refreshes only the streams that are asked for: a render in a mode the model was not
+    trained in must still use the trained parameters."""
+    from nerf_few_shot_limitations_amd.training import FusedStep
+    model, _ = make_model(N, "bf16", scene="solid")
+    c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
+    before, _ = N.render_camera(model.eval(), 16, 16, O.focal_for(16), c2w, 2.0, 6.0, 16, mma_mode="f32")
+    R, S = 64, 16
+    x = O.positional_encoding(torch.from_numpy(O.uniform01(111, R * S * 3).reshape(R * S, 3) * 4 - 2).float(), 10).cuda()
+    z = torch.sort(torch.from_numpy(O.uniform01(112, R * S).reshape(R, S) * 4 + 2).float(), dim=-1).values.cuda()
+    rd = torch.from_numpy(O.uniform01(113, R * 3).reshape(R, 3) - 0.5).float().cuda()
+    tgt = torch.ones(R, 3).cuda()
+    step = FusedStep(model.train(), lr=1e-2)
+    for _ in range(3):
+        step(x, z, rd, tgt)
+    after, _ = N.render_camera(model.eval(), 16, 16, O.focal_for(16), c2w, 2.0, 6.0, 16, mma_mode="f32")
+    ref = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode="f32")
+    ref.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    want, _ = N.render_camera(ref.cuda().eval(), 16, 16, O.focal_for(16), c2w, 2.0, 6.0, 16)
+    assert not torch.equal(before, after)
+    assert torch.equal(after, want)
+
+
+def test_training_entry_points_take_empty_batches(N):
+    from nerf_few_shot_limitations_amd import _lib as L
+    model, _ = make_model(N, "bf16")
+    x, g = inputs(8)
+    run_raw(N, model, x, g)                                   # builds the training state
+    h = model._handle
+    assert L.lib().nrf_train_context_bytes(h, 0, 0) == 0
+    assert L.lib().nrf_mlp_forward_train_v1(h, 0, None, 0, None, None, 0, None) == 0
+    assert L.lib().nrf_mlp_backward_v1(h, 0, None, None, 0, None, 0, None, None) == 0
+    assert L.lib().nrf_composite_backward(None, 3, None, 1, None, None, 0, 8, 0, None, None, None, None, 3, None, 1, None) == 0

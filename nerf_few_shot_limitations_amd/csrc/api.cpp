@@ -202,6 +202,7 @@ int ensure_train(nrf_model* m) {
     for (int i = 0; i < m->train.n_slots; ++i) m->train.slot_tiles[i] = m->tplan.slot_tiles[i];
     m->train.n_mask_slots = m->tplan.n_mask_slots;
     m->train.aux_floats = m->tplan.aux_floats;
+    m->train.cu_count = m->net.cu_count;
     m->train.n_params = m->layout.total;
     m->train_ready = true;
     return NRF_OK;

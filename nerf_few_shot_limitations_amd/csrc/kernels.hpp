@@ -85,6 +85,7 @@ struct TrainDev {
     int slot_tiles[kMaxSlots];  // feature tiles per saved-tensor slot
     int n_mask_slots;           // ReLU-mask bit planes (one per masked layer)
     int aux_floats;             // extra fp32 values saved per sample (V3: the softmax gate)
+    int cu_count;               // sizes the weight-gradient partial sums (one block per workgroup)
     int n_jobs;
     int job_x_slot[kMaxJobs], job_dz_slot[kMaxJobs], job_KT[kMaxJobs], job_MT[kMaxJobs], job_x_first[kMaxJobs];
     int64_t n_params;

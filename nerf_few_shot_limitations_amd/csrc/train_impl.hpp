@@ -7,13 +7,15 @@
 //                          from the saved activations, every dZ tile saved;
 //   weight_grad_kernel     dW = dZ X^T, db = sum dZ over the samples: per Linear one 256 x 256 (or smaller) output
 //                          held in the accumulators of a workgroup, the sample axis split over workgroups, partial
-//                          sums added to the flat gradient vector with fp32 atomics;
+//                          sums left in the context and added up in a fixed order by weight_grad_reduce_kernel;
 //   repack_kernel          flat fp32 parameters -> the packed operand streams (after every optimizer step);
 //   adam_kernel            torch.optim.Adam's update on the flat vectors (train.py:113-118).
 //
 // LANE <-> SAMPLE here (not ray): a training batch is a few thousand rays (baseline.yaml:32), so the sample
 // axis, not the ray axis, has to fill the chip; compositing and its backward are the staged kernels.
 #pragma once
+#include <algorithm>
+
 #include "fused_impl.hpp"
 #include "train_core.hpp"
 
@@ -38,6 +40,7 @@ struct TrainKArgs {
     int slot_tiles[kMaxSlots];
     int64_t mask_off[kMaxMaskSlots];   // ReLU-mask bit planes: kMaskBytes per sample tile each
     int64_t aux_off;                   // V3: (padded samples, 2) fp32 softmax gate
+    int64_t partial_off;               // weight-gradient partial sums: one kPartialFloats block per workgroup
 };
 
 // ---- host-side helpers shared by train_v1.hip / train_v2.hip -------------------------------------------------
@@ -46,6 +49,33 @@ constexpr int kWgSamples = 256;          // the context is laid out for whole 25
 inline int64_t tiles32(int64_t n) { return (n + kWgSamples - 1) / kWgSamples * (kWgSamples / 32); }
 
 inline int tile_bytes_of(int mode) { return mode == NRF_MMA_F32 ? 4 * kFragBytes : 2 * kFragBytes; }
+
+// Weight-gradient grid (weight_grad_kernel): one workgroup per CU (128 KiB of LDS); small batches get ONE round of
+// workgroups, large ones two.  The workgroups of a round are dealt to the jobs in proportion to the bytes a job reads per
+// sample (KT + MT saved tiles, with a floor: a stage costs a load latency + a barrier however few tiles it moves), so that
+// all of them finish together and the grid never exceeds the round (a 257th workgroup would run alone after the other 256).
+// Returns the grid size; first_block[j] .. first_block[j+1] are job j's workgroups.
+constexpr int kPartialFloats = 8 * 8 * 16 * 64 + 8 * 32;      // a workgroup's 256 x 256 accumulators + its 8 bias rows of 32
+
+inline int wgrad_grid(const TrainDev& t, int mode, int64_t n_tiles32, int* first_block) {
+    const int ST = mode == NRF_MMA_F32 ? 1 : 2;
+    const int rounds = n_tiles32 >= 8192 ? 2 : 1;
+    constexpr int min_stages = 4, cost_floor = 10;
+    const int64_t max_splits = std::max<int64_t>(1, (n_tiles32 + min_stages * ST - 1) / (min_stages * ST));
+    const int budget = rounds * t.cu_count;      // fewer workgroups were measured slower at every batch size (75 %: equal, 50 %: +10 %)
+    auto cost = [&](int j) { return std::max(t.job_KT[j] + t.job_MT[j], cost_floor); };
+    int cost_sum = 0;
+    for (int j = 0; j < t.n_jobs; ++j) cost_sum += cost(j);
+    int next = 0;
+    for (int j = 0; j < t.n_jobs; ++j) {
+        int64_t sp = (int64_t)budget * cost(j) / std::max(cost_sum, 1);      // floor: the sum stays within the budget
+        sp = std::max<int64_t>(1, std::min<int64_t>(sp, max_splits));
+        if (first_block) first_block[j] = next;
+        next += (int)sp;
+    }
+    if (first_block) first_block[t.n_jobs] = next;
+    return next;
+}
 
 inline bool fill_slots(const TrainDev& t, int mode, int64_t n, TrainKArgs& k, std::string& err) {
     if (t.n_slots < 1 || t.n_slots > kMaxSlots) { err = "training plan missing"; return false; }
@@ -62,6 +92,8 @@ inline bool fill_slots(const TrainDev& t, int mode, int64_t n, TrainKArgs& k, st
         off += nt * kFragBytes;
     }
     k.aux_off = off;
+    off += nt * 32 * (int64_t)t.aux_floats * 4;
+    k.partial_off = off;
     return true;
 }
 
@@ -256,6 +288,7 @@ struct GradJob {
 
 struct GradKArgs {
     const char* ctx;
+    float* partial;             // per-workgroup partial sums (kPartialFloats each), reduced by weight_grad_reduce_kernel
     float* grad;                // flat gradient vector, accumulated into
     const int32_t* maps;
     GradJob jobs[kMaxJobs];
@@ -345,29 +378,22 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
             }
         }
     }
-    // flush: accumulator tile rows = dZ features (registers), columns = X features (lanes)
-    const int32_t* row_w = P.maps + J.map_off;
-    const int32_t* row_b = row_w + 320;
-    const int32_t* colm = row_b + 320;
+    // hand the partial sums over: [wave][tile i*CT+j][register group of 4][lane][4 floats], 16 B per lane and store
+    float* part = P.partial + (int64_t)blockIdx.x * kPartialFloats;
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
         if (row0 + i >= J.MT) continue;
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
             if (col0 + j >= J.KT) continue;
-            const int col = colm[32 * (col0 + j) + c];
+            f32x4* dst = (f32x4*)(part + ((wave * 8 + i * CT + j) * 16) * 64) + lane;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = 32 * (row0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int w = row_w[o];
-                if (w >= 0 && col >= 0) unsafeAtomicAdd(P.grad + w + col, acc[i][j][r]);
-            }
+            for (int q = 0; q < 4; ++q) dst[q * 64] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
         }
     }
     if (has_z) {                                                   // bias: the wave that transposed dZ tile `wave` summed it
         const float s = bsum + __shfl_xor(bsum, 32, 64);
-        const int b = row_b[32 * wave + c];
-        if (h == 0 && b >= 0) unsafeAtomicAdd(P.grad + b, s);
+        if (h == 0) part[8 * 8 * 16 * 64 + 32 * wave + c] = s;
     }
 }
 

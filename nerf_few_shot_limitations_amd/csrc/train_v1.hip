@@ -43,6 +43,42 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// Second stage of the weight gradients: sum the workgroups' partial sums of a job in a fixed order and scatter them
+// through the job's row / column maps into the flat gradient vector.  One block per (job, wave, tile) = 16 registers x 64
+// lanes.  The only atomics left are the adds into `grad` (a weight shared by two jobs -- the fusion block of V3 -- receives
+// two of them; a + b = b + a, so the result does not depend on their order): gradients are bit-reproducible run to run.
+__global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const GradKArgs P) {
+    const int job = blockIdx.x >> 6, wt = blockIdx.x & 63, wave = wt >> 3, tile = wt & 7;
+    const GradJob J = P.jobs[job];
+    constexpr int RT = 2, CT = 4;
+    const int i = tile / CT, j = tile % CT;
+    const int row0 = (wave & 3) * RT, col0 = (wave >> 2) * CT;
+    const int b0 = P.first_block[job], b1 = P.first_block[job + 1];
+    const int32_t* row_w = P.maps + J.map_off;
+    const int32_t* row_b = row_w + 320;
+    const int32_t* colm = row_b + 320;
+    if (row0 + i < J.MT && col0 + j < J.KT) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = threadIdx.x + 256 * k;                       // element of the tile's [q][lane][4] block
+            const int q = e >> 8, lane = (e >> 2) & 63, sub = e & 3, r = 4 * q + sub, c = lane & 31, h = lane >> 5;
+            const float* src = P.partial + (int64_t)b0 * kPartialFloats + (wave * 8 + tile) * 16 * 64 + e;
+            float s = 0.0f;
+            for (int b = b0; b < b1; ++b, src += kPartialFloats) s += *src;
+            const int o = 32 * (row0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int w = row_w[o], col = colm[32 * (col0 + j) + c];
+            if (w >= 0 && col >= 0) unsafeAtomicAdd(P.grad + w + col, s);
+        }
+    }
+    if (tile == 0 && wave < J.MT && threadIdx.x < 32) {
+        const float* src = P.partial + (int64_t)b0 * kPartialFloats + 8 * 8 * 16 * 64 + 32 * wave + threadIdx.x;
+        float s = 0.0f;
+        for (int b = b0; b < b1; ++b, src += kPartialFloats) s += *src;
+        const int bo = row_b[32 * wave + threadIdx.x];
+        if (bo >= 0) unsafeAtomicAdd(P.grad + bo, s);
+    }
+}
+
 namespace {
 
 template <class Mode, int WAVES>
@@ -79,6 +115,10 @@ int run_train_backward(const DeviceNet& net, const TrainDev& t, int mode, TrainK
     return NRF_OK;
 }
 
+template <class Mode> constexpr int mode_of() { return NRF_MMA_F32; }
+template <> constexpr int mode_of<ModeBF16>() { return NRF_MMA_BF16; }
+template <> constexpr int mode_of<ModeF16>() { return NRF_MMA_F16; }
+
 template <class Mode, int ST>
 int run_weight_grad(const DeviceNet& net, const TrainDev& t, const TrainKArgs& k, float* grad, hipStream_t s, std::string& err) {
     auto kernel = weight_grad_kernel<Mode, ST>;
@@ -97,28 +137,10 @@ int run_weight_grad(const DeviceNet& net, const TrainDev& t, const TrainKArgs& k
         g.jobs[j].x_first = t.job_x_first[j];
         g.jobs[j].map_off = j * kMapStride;
     }
-    // One workgroup per CU (128 KiB of LDS), and every workgroup ends with up to 64 Ki atomic adds: small batches get ONE
-    // round of workgroups, large ones two.  The workgroups of a round are dealt to the jobs in proportion to the bytes a
-    // job reads per sample (KT + MT saved tiles), so that all of them finish together and the grid never exceeds the
-    // round (a 257th workgroup would run alone after the other 256).
-    const int rounds = g.n_tiles32 >= 8192 ? 2 : 1;
-    constexpr int min_stages = 4;
-    const int64_t max_splits = std::max<int64_t>(1, (g.n_tiles32 + min_stages * ST - 1) / (min_stages * ST));
-    const int budget = rounds * net.cu_count;      // fewer workgroups were measured slower at every batch size (75 %: equal, 50 %: +10 %)
-    static const int cost_floor = [] { const char* e = getenv("NRF_WGRAD_COST_FLOOR"); return e ? atoi(e) : 10; }();
-    auto cost = [&](int j) { return std::max(t.job_KT[j] + t.job_MT[j], cost_floor); };   // a stage costs a load latency + a barrier however few tiles it moves
-    int cost_sum = 0;
-    for (int j = 0; j < t.n_jobs; ++j) cost_sum += cost(j);
-    int next = 0;
-    for (int j = 0; j < t.n_jobs; ++j) {
-        int64_t sp = (int64_t)budget * cost(j) / cost_sum;      // floor: the sum stays within the budget
-        sp = std::max<int64_t>(1, std::min<int64_t>(sp, max_splits));
-        g.first_block[j] = next;
-        next += (int)sp;
-    }
-    g.first_block[t.n_jobs] = next;
-    const unsigned grid = (unsigned)next;
+    const unsigned grid = (unsigned)wgrad_grid(t, mode_of<Mode>(), g.n_tiles32, g.first_block);
+    g.partial = (float*)(k.ctx + k.partial_off);
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(512), kLds, s, g);
+    hipLaunchKernelGGL(weight_grad_reduce_kernel, dim3((unsigned)(64 * t.n_jobs)), dim3(256), 0, s, g);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("weight gradient launch: ") + hipGetErrorString(e); return NRF_EHIP; }
     return NRF_OK;
@@ -135,7 +157,10 @@ bool check_train(const DeviceNet& net, const TrainDev& t, int mode, std::string&
 int64_t train_ctx_bytes(const TrainDev& t, int mode, int64_t n) {
     int64_t tiles = 0;
     for (int i = 0; i < t.n_slots; ++i) tiles += t.slot_tiles[i];
-    return tiles32(n) * (tiles * tile_bytes_of(mode) + (int64_t)t.n_mask_slots * kFragBytes + 32 * (int64_t)t.aux_floats * 4);
+    if (n <= 0) return 0;
+    const int64_t nt = tiles32(n);
+    return nt * (tiles * tile_bytes_of(mode) + (int64_t)t.n_mask_slots * kFragBytes + 32 * (int64_t)t.aux_floats * 4) +
+           (int64_t)wgrad_grid(t, mode, nt, nullptr) * kPartialFloats * 4;
 }
 
 int launch_train_forward(const DeviceNet& net, const TrainDev& t, int mode, const float* x_enc, int64_t n, float* out4, void* ctx,

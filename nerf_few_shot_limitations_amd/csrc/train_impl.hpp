@@ -4,7 +4,7 @@
 //   train_forward_kernel   forward chain of fused_impl.hpp's staged forward, one 32-sample tile per wave, which also
 //                          saves every layer's operand tiles (train_core.hpp);
 //   train_backward_kernel  dZ chain: head^T, then layers.{n-1..1}^T streamed like the forward weights, ReLU' taken
-//                          from the saved activations, every dZ tile saved;
+//                          from the forward's bit planes, every dZ tile saved;
 //   weight_grad_kernel     dW = dZ X^T, db = sum dZ over the samples: per Linear one 256 x 256 (or smaller) output
 //                          held in the accumulators of a workgroup, the sample axis split over workgroups, partial
 //                          sums left in the context and added up in a fixed order by weight_grad_reduce_kernel;

@@ -58,16 +58,18 @@ __global__ void __launch_bounds__(256) weight_grad_reduce_kernel(const GradKArgs
     const int32_t* row_b = row_w + 320;
     const int32_t* colm = row_b + 320;
     if (row0 + i < J.MT && col0 + j < J.KT) {
+        // thread t: register group q = t >> 6, lane = t & 63: the 16 bytes that lane stored for registers 4q .. 4q+3
+        const int q = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+        const f32x4* src = (const f32x4*)(P.partial + (int64_t)b0 * kPartialFloats + (wave * 8 + tile) * 16 * 64) + threadIdx.x;
+        f32x4 s = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int b = b0; b < b1; ++b, src += kPartialFloats / 4) s += *src;
+        const int col = colm[32 * (col0 + j) + c];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = threadIdx.x + 256 * k;                       // element of the tile's [q][lane][4] block
-            const int q = e >> 8, lane = (e >> 2) & 63, sub = e & 3, r = 4 * q + sub, c = lane & 31, h = lane >> 5;
-            const float* src = P.partial + (int64_t)b0 * kPartialFloats + (wave * 8 + tile) * 16 * 64 + e;
-            float s = 0.0f;
-            for (int b = b0; b < b1; ++b, src += kPartialFloats) s += *src;
+        for (int sub = 0; sub < 4; ++sub) {
+            const int r = 4 * q + sub;
             const int o = 32 * (row0 + i) + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const int w = row_w[o], col = colm[32 * (col0 + j) + c];
-            if (w >= 0 && col >= 0) unsafeAtomicAdd(P.grad + w + col, s);
+            const int w = row_w[o];
+            if (w >= 0 && col >= 0) unsafeAtomicAdd(P.grad + w + col, s[sub]);
         }
     }
     if (tile == 0 && wave < J.MT && threadIdx.x < 32) {
@@ -170,9 +172,10 @@ int launch_train_forward(const DeviceNet& net, const TrainDev& t, int mode, cons
     TrainKArgs k{};
     k.x_enc = x_enc; k.n = n; k.out4 = out4; k.ctx = (char*)ctx;
     if (!fill_slots(t, mode, n, k, err)) return NRF_EINVAL;
+    const bool small = small_batch(net, n);
     switch (mode) {
-        case NRF_MMA_BF16: return run_train_forward<ModeBF16, 8>(net, mode, k, s, err);
-        case NRF_MMA_F16:  return run_train_forward<ModeF16, 8>(net, mode, k, s, err);
+        case NRF_MMA_BF16: return small ? run_train_forward<ModeBF16, 4>(net, mode, k, s, err) : run_train_forward<ModeBF16, 8>(net, mode, k, s, err);
+        case NRF_MMA_F16:  return small ? run_train_forward<ModeF16, 4>(net, mode, k, s, err) : run_train_forward<ModeF16, 8>(net, mode, k, s, err);
         default:           return run_train_forward<ModeF32, 4>(net, mode, k, s, err);
     }
 }
@@ -185,9 +188,10 @@ int launch_train_backward(const DeviceNet& net, const TrainDev& t, int mode, con
     k.n = n; k.out4 = const_cast<float*>(out4); k.g_out4 = g_out4; k.ctx = (char*)ctx;
     if (!fill_slots(t, mode, n, k, err)) return NRF_EINVAL;
     int r;
+    const bool small = small_batch(net, n);
     switch (mode) {
-        case NRF_MMA_BF16: r = run_train_backward<ModeBF16, 8>(net, t, mode, k, s, err); break;
-        case NRF_MMA_F16:  r = run_train_backward<ModeF16, 8>(net, t, mode, k, s, err); break;
+        case NRF_MMA_BF16: r = small ? run_train_backward<ModeBF16, 4>(net, t, mode, k, s, err) : run_train_backward<ModeBF16, 8>(net, t, mode, k, s, err); break;
+        case NRF_MMA_F16:  r = small ? run_train_backward<ModeF16, 4>(net, t, mode, k, s, err) : run_train_backward<ModeF16, 8>(net, t, mode, k, s, err); break;
         default:           r = run_train_backward<ModeF32, 4>(net, t, mode, k, s, err); break;
     }
     if (r != NRF_OK) return r;

@@ -54,9 +54,10 @@ int launch_train_forward_v2(const DeviceNet& net, const TrainDev& t, int mode, c
     TrainKArgs k{};
     k.pos = pos; k.dir = dir; k.n = n; k.rgb = rgb; k.density = density; k.ctx = (char*)ctx;
     if (!fill_slots(t, mode, n, k, err)) return NRF_EINVAL;
+    const bool small = small_batch(net, n);
     switch (mode) {
-        case NRF_MMA_BF16: return run_forward<ModeBF16, 8>(net, mode, k, s, err);
-        case NRF_MMA_F16:  return run_forward<ModeF16, 8>(net, mode, k, s, err);
+        case NRF_MMA_BF16: return small ? run_forward<ModeBF16, 4>(net, mode, k, s, err) : run_forward<ModeBF16, 8>(net, mode, k, s, err);
+        case NRF_MMA_F16:  return small ? run_forward<ModeF16, 4>(net, mode, k, s, err) : run_forward<ModeF16, 8>(net, mode, k, s, err);
         default:           return run_forward<ModeF32, 4>(net, mode, k, s, err);
     }
 }
@@ -70,9 +71,10 @@ int launch_train_backward_v2(const DeviceNet& net, const TrainDev& t, int mode, 
     k.ctx = (char*)ctx;
     if (!fill_slots(t, mode, n, k, err)) return NRF_EINVAL;
     int r;
+    const bool small = small_batch(net, n);
     switch (mode) {
-        case NRF_MMA_BF16: r = run_backward<ModeBF16, 8>(net, t, mode, k, s, err); break;
-        case NRF_MMA_F16:  r = run_backward<ModeF16, 8>(net, t, mode, k, s, err); break;
+        case NRF_MMA_BF16: r = small ? run_backward<ModeBF16, 4>(net, t, mode, k, s, err) : run_backward<ModeBF16, 8>(net, t, mode, k, s, err); break;
+        case NRF_MMA_F16:  r = small ? run_backward<ModeF16, 4>(net, t, mode, k, s, err) : run_backward<ModeF16, 8>(net, t, mode, k, s, err); break;
         default:           r = run_backward<ModeF32, 4>(net, t, mode, k, s, err); break;
     }
     if (r != NRF_OK) return r;

@@ -50,16 +50,17 @@ bool check(const DeviceNet& net, const TrainDev& t, int mode, std::string& err) 
 }
 
 #define NRF_V3_DISPATCH(FN, ...)                                                          \
+    const bool small = small_batch(net, k.n);                                             \
     if (net.arch.dino_dim == 64) {                                                        \
         switch (mode) {                                                                   \
-            case NRF_MMA_BF16: return FN<ModeBF16, 8, 2>(__VA_ARGS__);                    \
-            case NRF_MMA_F16:  return FN<ModeF16, 8, 2>(__VA_ARGS__);                     \
+            case NRF_MMA_BF16: return small ? FN<ModeBF16, 4, 2>(__VA_ARGS__) : FN<ModeBF16, 8, 2>(__VA_ARGS__);   \
+            case NRF_MMA_F16:  return small ? FN<ModeF16, 4, 2>(__VA_ARGS__) : FN<ModeF16, 8, 2>(__VA_ARGS__);     \
             default:           return FN<ModeF32, 4, 2>(__VA_ARGS__);                     \
         }                                                                                 \
     }                                                                                     \
     switch (mode) {                                                                       \
-        case NRF_MMA_BF16: return FN<ModeBF16, 8, 4>(__VA_ARGS__);                        \
-        case NRF_MMA_F16:  return FN<ModeF16, 8, 4>(__VA_ARGS__);                         \
+        case NRF_MMA_BF16: return small ? FN<ModeBF16, 4, 4>(__VA_ARGS__) : FN<ModeBF16, 8, 4>(__VA_ARGS__);       \
+        case NRF_MMA_F16:  return small ? FN<ModeF16, 4, 4>(__VA_ARGS__) : FN<ModeF16, 8, 4>(__VA_ARGS__);         \
         default:           return FN<ModeF32, 4, 4>(__VA_ARGS__);                         \
     }
 

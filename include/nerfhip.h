@@ -262,6 +262,10 @@ int nrf_composite_backward(const float* rgb, int rgb_stride, const float* sigma,
                            const float* g_rgb, const float* g_depth, const float* g_weights,
                            float* d_rgb, int d_rgb_stride, float* d_sigma, int d_sigma_stride, void* stream);
 
+/* `rgb_weight * nn.MSELoss()(pred, target)` (train.py:36-44) and its gradient in one launch: loss[0] = weight * mean((pred -
+ * target)^2) over n values, g_pred = d loss / d pred.  n <= 2^22 (ray batches). */
+int nrf_mse_grad(const float* pred, const float* target, int64_t n, float weight, float* g_pred, float* loss, void* stream);
+
 /* torch.optim.Adam's update (train.py:113-118; no amsgrad) on flat vectors;
  * step counts from 1. */
 int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

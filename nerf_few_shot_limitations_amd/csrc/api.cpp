@@ -452,6 +452,20 @@ int nrf_model_update_device(nrf_model* m, const float* flat_params, int mode_mas
     int rc = ensure_sources(m);
     if (rc != NRF_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
+    if (mode_mask == 1 || mode_mask == 2 || mode_mask == 4) {
+        // the per-step case: one mode -> forward stream, backward stream (once training is set up) and bias table in one launch
+        const int mode = mode_mask == 1 ? 0 : (mode_mask == 2 ? 1 : 2);
+        const int f32 = mode == NRF_MMA_F32;
+        const int32_t* src[3] = {m->d_src[0][f32], m->train_ready ? m->d_src[1][f32] : nullptr, m->d_bias_src};
+        const int64_t n[3] = {m->n_src[0][f32], m->n_src[1][f32], m->plan.n_bias};
+        const int modes[3] = {mode, mode, NRF_MMA_F32};
+        void* out[3] = {m->d_stream[mode], m->d_bstream[mode], m->d_bias};
+        rc = nrf::launch_repack3(flat_params, src, n, modes, out, s);
+        if (rc != NRF_OK) return fail(rc, "repack launch failed");
+        m->lin_stale = true;
+        for (int k = 0; k < 3; ++k) m->bfresh[k] = (k == mode) && m->train_ready;
+        return NRF_OK;
+    }
     for (int mode = 0; mode < 3; ++mode) {
         if (!(mode_mask & (1 << mode))) continue;
         const int f32 = mode == NRF_MMA_F32;
@@ -564,6 +578,13 @@ int nrf_composite_backward(const float* rgb, int rgb_stride, const float* sigma,
     const int r = nrf::launch_composite_backward(rgb, rgb_stride, sigma, sigma_stride, z_vals, rays_d, n_rays, n_samples, white_bkgd, g_rgb,
                                                  g_depth, g_weights, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, (hipStream_t)stream);
     return r == NRF_OK ? NRF_OK : fail(r, "composite backward launch failed");
+}
+
+int nrf_mse_grad(const float* pred, const float* target, int64_t n, float weight, float* g_pred, float* loss, void* stream) {
+    if (n <= 0 || n > ((int64_t)1 << 22)) return fail(NRF_EINVAL, "nrf_mse_grad: n must be in 1 .. 2^22");
+    if (!pred || !target || !g_pred || !loss) return fail(NRF_EINVAL, "null pointer");
+    const int r = nrf::launch_mse_grad(pred, target, n, weight, g_pred, loss, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "mse launch failed");
 }
 
 int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,

@@ -382,6 +382,34 @@ int launch_composite_backward(const float* rgb, int rgb_stride, const float* sig
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 
+// loss = w * mean((pred - target)^2) and d loss / d pred in one launch (train.py:36-44: rgb_weight * nn.MSELoss()).
+// One block: the reference's ray batches are a few thousand values; fixed summation order.
+__global__ void __launch_bounds__(1024) mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target, int n, float weight,
+                                                        float* __restrict__ g_pred, float* __restrict__ loss) {
+    __shared__ float part[16];
+    const float scale = 2.0f * weight / (float)n;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float d = pred[i] - target[i];
+        g_pred[i] = scale * d;
+        s += d * d;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int k = 0; k < 16; ++k) t += part[k];
+        *loss = weight * t / (float)n;
+    }
+}
+
+int launch_mse_grad(const float* pred, const float* target, int64_t n, float weight, float* g_pred, float* loss, hipStream_t s) {
+    if (n <= 0 || n > (1 << 22)) return NRF_EINVAL;
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(1024), 0, s, pred, target, (int)n, weight, g_pred, loss);
+    return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
+}
+
 int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, float* samples, float* z_union,
                       hipStream_t s) {
     if (n_rays <= 0) return NRF_OK;

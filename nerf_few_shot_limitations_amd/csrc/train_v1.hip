@@ -26,6 +26,31 @@ __global__ void __launch_bounds__(256) repack32_kernel(const float* __restrict__
     }
 }
 
+// forward stream, backward stream and bias table in ONE launch (an optimisation step re-packs all three): segment k holds
+// n[k] work items -- pairs of 16-bit elements, or single fp32 values when mode[k] is NRF_MMA_F32
+struct Repack3Args {
+    const int32_t* src[3];
+    void* out[3];
+    int64_t n[3];
+    int mode[3];
+};
+__global__ void __launch_bounds__(256) repack3_kernel(const float* __restrict__ flat, const Repack3Args a) {
+    const int64_t total = a.n[0] + a.n[1] + a.n[2];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int k = 0;
+        int64_t j = i;
+        if (j >= a.n[0]) { j -= a.n[0]; k = 1; if (j >= a.n[1]) { j -= a.n[1]; k = 2; } }
+        if (a.mode[k] == NRF_MMA_F32) {
+            const int sidx = a.src[k][j];
+            ((float*)a.out[k])[j] = sidx >= 0 ? flat[sidx] : 0.0f;
+        } else {
+            const int2 sp = *(const int2*)(a.src[k] + 2 * j);
+            const float x = sp.x >= 0 ? flat[sp.x] : 0.0f, y = sp.y >= 0 ? flat[sp.y] : 0.0f;
+            ((uint32_t*)a.out[k])[j] = a.mode[k] == NRF_MMA_BF16 ? (uint32_t)pack_pair<bf16x2, false>(x, y) : (uint32_t)pack_pair<f16x2, false>(x, y);
+        }
+    }
+}
+
 // torch.optim.Adam (train.py:113-118; no amsgrad, weight decay added to the gradient, bias-corrected moments):
 //   g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -216,6 +241,20 @@ int launch_repack(const float* flat, const int32_t* src, int64_t n_elems, int mo
         hipLaunchKernelGGL(repack16_kernel, dim3((unsigned)((pairs + 255) / 256 < 4096 ? (pairs + 255) / 256 : 4096)), dim3(256), 0, s, flat, src, pairs,
                            mode == NRF_MMA_BF16 ? 1 : 0, (uint32_t*)out);
     }
+    return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
+}
+
+int launch_repack3(const float* flat, const int32_t* const src[3], const int64_t n_elems[3], const int modes[3], void* const out[3], hipStream_t s) {
+    Repack3Args a{};
+    int64_t total = 0;
+    for (int k = 0; k < 3; ++k) {
+        a.src[k] = src[k]; a.out[k] = out[k]; a.mode[k] = modes[k];
+        a.n[k] = src[k] ? (modes[k] == NRF_MMA_F32 ? n_elems[k] : n_elems[k] / 2) : 0;
+        total += a.n[k];
+    }
+    if (total <= 0) return NRF_OK;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(repack3_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, s, flat, a);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 

@@ -437,9 +437,13 @@ class FusedStep:
                 L.check(lib.nrf_composite(L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, self.white,
                                           L.ptr(self.pred), None, None, st))
             # loss = w * mean((pred - target)^2) over R*3 elements; d loss / d pred = 2 w (pred - target) / (3 R)
-            torch.sub(self.pred, tgt, out=self.g_pred)
-            loss = self.g_pred.square().mean() * self.rgb_weight
-            self.g_pred.mul_(2.0 * self.rgb_weight / (3 * R))
+            if 3 * R <= (1 << 22):
+                loss = torch.empty((), dtype=torch.float32, device=dev)
+                L.check(lib.nrf_mse_grad(L.ptr(self.pred), L.ptr(tgt), 3 * R, self.rgb_weight, L.ptr(self.g_pred), L.ptr(loss), st))
+            else:
+                torch.sub(self.pred, tgt, out=self.g_pred)
+                loss = self.g_pred.square().mean() * self.rgb_weight
+                self.g_pred.mul_(2.0 * self.rgb_weight / (3 * R))
             if v2:
                 L.check(lib.nrf_composite_backward(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(self.g_pred), None, None,
                                                    L.ptr(g_rgb), 3, L.ptr(g_den), 1, st))

@@ -893,3 +893,18 @@ def test_training_entry_points_take_empty_batches(N):
     assert L.lib().nrf_mlp_forward_train_v1(h, 0, None, 0, None, None, 0, None) == 0
     assert L.lib().nrf_mlp_backward_v1(h, 0, None, None, 0, None, 0, None, None) == 0
     assert L.lib().nrf_composite_backward(None, 3, None, 1, None, None, 0, 8, 0, None, None, None, None, 3, None, 1, None) == 0
+
+
+@pytest.mark.parametrize("n", [3, 6144, 100003])
+def test_mse_grad_kernel_matches_torch(N, n):
+    from nerf_few_shot_limitations_amd import _lib as L
+    pred = torch.from_numpy(O.uniform01(121, n)).float().cuda().requires_grad_(True)
+    tgt = torch.from_numpy(O.uniform01(122, n)).float().cuda()
+    ref = 0.7 * torch.nn.functional.mse_loss(pred, tgt)
+    ref.backward()
+    g = torch.empty(n, device="cuda")
+    loss = torch.empty((), device="cuda")
+    L.check(L.lib().nrf_mse_grad(L.ptr(pred.detach()), L.ptr(tgt), n, 0.7, L.ptr(g), L.ptr(loss), L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
+    assert (g - pred.grad).abs().max() < 1e-7

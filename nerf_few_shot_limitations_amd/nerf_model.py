@@ -106,6 +106,14 @@ class NeRFMLP(nn.Module):
 
     # ---- parameters in the order include/nerfhip.h documents ------------------------------------
     def linears(self):
+        cached = self.__dict__.get("_linears_cache")        # the module tree is fixed after __init__; this list is asked for several times per step
+        if cached is not None:
+            return cached
+        out = self._build_linears()
+        self.__dict__["_linears_cache"] = out
+        return out
+
+    def _build_linears(self):
         if self.net == L.NRF_NET_V1:
             return list(self.layers) + [self.sigma_out, self.rgb_out]
         out = []

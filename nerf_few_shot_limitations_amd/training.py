@@ -32,9 +32,12 @@ class FlatParams:
         self.module = module
         self.flat = None
         self.offsets = []
+        self._params = None
 
     def params(self):
-        return [p for m in self.module.linears() for p in (m.weight, m.bias)]
+        if self._params is None:                  # nn.Parameter objects are stable (only their storage is re-homed)
+            self._params = [p for m in self.module.linears() for p in (m.weight, m.bias)]
+        return self._params
 
     def ensure(self):
         ps = self.params()
@@ -202,7 +205,6 @@ def mlp_v2_train(module, positions, directions, dino_features=None):
             raise NotImplementedError("no gradient with respect to the DINO features is produced (the feature extractor, LoRA "
                                       "included, is outside the HIP path: SURVEY.md section 8 f4); detach them")
         dino = L.dev_f32(dino_features, pos.device).reshape(-1, module.dino_dim)
-    module.flat_params().ensure()
     return _MLPV2Fn.apply(module, pos, dirs, dino, *module.flat_params().params())
 
 
@@ -211,7 +213,6 @@ def mlp_v1_train(module, x_enc):
     x = L.dev_f32(x_enc)
     pe = 3 * (2 * module.pos_freq + 1)
     flat_in = x.reshape(-1, pe)
-    module.flat_params().ensure()
     out = _MLPV1Fn.apply(module, flat_in, *module.flat_params().params())
     return out.reshape(*x.shape[:-1], 4)
 

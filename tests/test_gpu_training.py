@@ -905,3 +905,20 @@ def test_mse_grad_kernel_matches_torch(N, n):
     torch.cuda.synchronize()
     assert abs(loss.item() - ref.item()) < 1e-6 * max(1.0, abs(ref.item()))
     assert (g - pred.grad).abs().max() < 1e-7
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_gradient_is_additive_over_the_batch_at_scale(N, mode):
+    """Size-independent property at a batch no CPU check could cover (131 072 samples, 8-wave kernels in bf16): every
+    sample's chain is independent of its neighbours, so grad(batch) = grad(first half) + grad(second half) up to fp32
+    summation order -- in the 16-bit modes too -- and scaling the incoming gradient scales the result."""
+    n = 131072
+    model, _ = make_model(N, mode, scene="solid")
+    x, g = inputs(n, seed=61)
+    _, full, _ = run_raw(N, model, x, g)
+    _, a, _ = run_raw(N, model, x[: n // 2], g[: n // 2])
+    _, b, _ = run_raw(N, model, x[n // 2:], g[n // 2:])
+    assert rel_to_max(a + b, full) < 2e-5
+    if mode == "f32":
+        _, half, _ = run_raw(N, model, x, 0.5 * g)            # exact in fp32: a power-of-two factor commutes with every rounding
+        assert torch.equal(half * 2, full)

@@ -41,7 +41,10 @@ def training_line(N, args, dev):
     from nerf_few_shot_limitations_amd.training import FusedStep
     R, S = 2048, 32
     torch.manual_seed(0)
-    if args.net == "v2":
+    if args.net == "v3":
+        m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=args.mode).to(dev).train()
+        pts = torch.rand(R * S, 3, device=dev) * 4 - 2
+    elif args.net == "v2":
         m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=args.mode).to(dev).train()
         pts = torch.rand(R * S, 3, device=dev) * 4 - 2
     else:
@@ -52,7 +55,9 @@ def training_line(N, args, dev):
     d = torch.rand(R, 3, device=dev) - 0.5
     tgt = torch.rand(R, 3, device=dev)
     step = FusedStep(m, lr=5e-4, weight_decay=1e-6)
-    kw = dict(dirs=dirs) if args.net == "v2" else {}
+    kw = dict(dirs=dirs) if args.net != "v1" else {}
+    if args.net == "v3":
+        kw["dino"] = torch.rand(R * S, 64, device=dev) * 2 - 1
     first = None
     for _ in range(3):
         loss = step(pts, z, d, tgt, **kw)
@@ -255,7 +260,7 @@ def main():
             "f32_max_abs_rgb": float((rgb32.cpu() - ref["rgb"]).abs().max()),
             "f32_max_abs_depth": float((depth32.cpu() - ref["depth"]).abs().max()),
         }
-    if rank == 0 and world == 1 and args.net in ("v1", "v2") and not args.no_train:
+    if rank == 0 and world == 1 and not args.no_train:
         out["training"] = training_line(N, args, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)

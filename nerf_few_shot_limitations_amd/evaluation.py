@@ -69,7 +69,7 @@ def evaluate_views(model, poses, H, W, focal, near, far, N_samples=64, targets=N
     tile_rays = 16 * int(W)
     local = tiles.render_tiles(model, H, W, focal, poses, near, far, N_samples, 0, 1, tile_rays, white_bkgd=white_bkgd,
                                mma_mode=mma_mode, ert_eps=ert_eps, dino=dino)
-    frames = tiles.gather_frames(local, int(H) * int(W), tile_rays)
+    frames = tiles.gather_frames(local, int(H) * int(W), tile_rays, world=1)      # rendered with rank 0 of 1: no collective
     images = frames[..., :3].reshape(V, H, W, 3)
     depth = frames[..., 3].reshape(V, H, W)
     out = {"images": images, "depth": depth, "per_view": []}

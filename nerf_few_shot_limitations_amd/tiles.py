@@ -126,10 +126,12 @@ def render_tiles(model, H, W, focal, c2w, near, far, N_samples, rank, world, til
     return job.pack()
 
 
-def gather_frames(local: torch.Tensor, n_rays: int, tile_rays: int, group=None) -> torch.Tensor:
-    """local (V, per_rank*tile_rays, C) on every rank -> (V, n_rays, C) on every rank with ONE all_gather."""
+def gather_frames(local: torch.Tensor, n_rays: int, tile_rays: int, group=None, world=None) -> torch.Tensor:
+    """local (V, per_rank*tile_rays, C) on every rank -> (V, n_rays, C) on every rank with ONE all_gather.
+    world=1: the caller rendered every tile itself (no collective, whatever process group happens to be initialised)."""
     import torch.distributed as dist
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
     V = local.shape[0]
     if world == 1:
         g = local[None]

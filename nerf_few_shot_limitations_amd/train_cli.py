@@ -71,8 +71,11 @@ def fetch_features(dino_struct, pts):
     return feats
 
 
-def train_epoch(step, cfg, epoch, images, poses, H, W, focal, near, far, gen, dino_maps=None, max_batches=None):
-    """One pass of train.py:261-290 over the training views; returns (mean loss, ray-samples processed)."""
+def train_epoch(step, cfg, epoch, images, poses, H, W, focal, near, far, gen, dino_maps=None, max_batches=None, rank=0, world=1):
+    """One pass of train.py:261-290 over the training views; returns (mean loss, ray-samples processed).
+    world > 1 (data parallel, `FusedStep(data_parallel=True)`): every rank draws the SAME shuffle (same generator seed) and
+    takes rays rank, rank+world, ... of each batch -- the batches are those of one process (the stratified jitter of a ray is
+    keyed by its position inside the call, so the sample depths differ from a single-process run's)."""
     Ht, Wt, S, batch = schedule_for(cfg, epoch)
     model = step.model
     use_dino = model.net == L.NRF_NET_V3
@@ -83,6 +86,10 @@ def train_epoch(step, cfg, epoch, images, poses, H, W, focal, near, far, gen, di
         order = torch.randperm(ro.shape[0], device=ro.device, generator=gen)
         for i in range(0, order.shape[0], batch):
             idx = order[i:i + batch]
+            if world > 1:
+                idx = idx[: idx.shape[0] // world * world][rank::world]        # equal shards: the all-reduce averages per-rank means
+                if idx.shape[0] == 0:
+                    continue
             o, d, t = ro[idx], rd[idx], tgt[idx]
             pts, z = sample_points_along_rays(o, d, near, far, S, perturb=True, seed=epoch * 1_000_003 + v * 10_007 + i)
             n = idx.shape[0]
@@ -120,7 +127,18 @@ def main(argv=None):
     ap.add_argument("--max-test-views", type=int, default=None)
     ap.add_argument("--max-batches", type=int, default=None, help="stop every epoch after this many ray batches (smoke runs)")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--data-parallel", action="store_true",
+                    help="launched with torch.distributed.run, one process per GPU: ray batches shard over the ranks, one all-reduce of the "
+                         "flat gradient vector per step (RCCL); rank 0 validates and writes")
     args = ap.parse_args(argv)
+    rank, world = 0, 1
+    if args.data_parallel:
+        import torch.distributed as dist
+        local = int(os.environ.get("NERF_TRAIN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(local)
+        if not dist.is_initialized():
+            dist.init_process_group(backend=os.environ.get("NERF_TRAIN_BACKEND", "nccl"))
+        rank, world = dist.get_rank(), dist.get_world_size()
 
     torch.manual_seed(args.seed)                          # parameter init (when no checkpoint is given) and the ray shuffles
     cfg = load_config(args.config)
@@ -156,7 +174,7 @@ def main(argv=None):
     model = model.to(dev).train()
     o, lw = cfg["optimizer"], cfg.get("loss", {})
     step = FusedStep(model, lr=float(o["lr"]), weight_decay=float(o["weight_decay"]), rgb_weight=float(lw.get("rgb_weight", 1.0)),
-                     white_bkgd=rs["white_bkgd"])
+                     white_bkgd=rs["white_bkgd"], data_parallel=world > 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed)
     best, log = 0.0, []
@@ -165,10 +183,13 @@ def main(argv=None):
     for epoch in range(epochs):
         step.opt.lr = lr_at(cfg, epoch)
         t0 = time.perf_counter()
-        loss, samples = train_epoch(step, cfg, epoch, images, poses, H, W, focal, rs["near"], rs["far"], gen, dino_maps, args.max_batches)
+        loss, samples = train_epoch(step, cfg, epoch, images, poses, H, W, focal, rs["near"], rs["far"], gen, dino_maps, args.max_batches, rank, world)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        rec = {"epoch": epoch + 1, "loss": loss, "lr": step.opt.lr, "seconds": round(dt, 3), "Msamples_per_s": round(samples / dt / 1e6, 2)}
+        rec = {"epoch": epoch + 1, "loss": loss, "lr": step.opt.lr, "seconds": round(dt, 3), "Msamples_per_s": round(world * samples / dt / 1e6, 2)}
+        if rank != 0:                                                         # every rank holds the same parameters: rank 0 validates and writes
+            log.append(rec)
+            continue
         if (epoch + 1) % int(cfg["output"]["val_freq"]) == 0 or epoch + 1 == epochs:
             m = evaluate_views(model, test_poses, H, W, focal, rs["near"], rs["far"], rs["n_samples"], targets=targets, white_bkgd=rs["white_bkgd"],
                                mma_mode=args.mode, dino=eval_dino, out_dir=os.path.join(out_dir, f"val_{epoch + 1}"))
@@ -181,9 +202,14 @@ def main(argv=None):
             save_checkpoint(os.path.join(out_dir, f"epoch_{epoch + 1}.pth"), model, step, epoch, best, cfg)
         log.append(rec)
         print(json.dumps(rec), flush=True)
-    os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "train_log.json"), "w") as f:
-        json.dump(log, f, indent=1)
+    if rank == 0:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "train_log.json"), "w") as f:
+            json.dump(log, f, indent=1)
+    if args.data_parallel:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     return log
 
 

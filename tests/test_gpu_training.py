@@ -922,3 +922,40 @@ def test_gradient_is_additive_over_the_batch_at_scale(N, mode):
     if mode == "f32":
         _, half, _ = run_raw(N, model, x, 0.5 * g)            # exact in fp32: a power-of-two factor commutes with every rounding
         assert torch.equal(half * 2, full)
+
+
+def test_train_cli_data_parallel_matches_one_process(N, tmp_path):
+    """`--data-parallel` under torch.distributed.run with two ranks (gloo, sharing the test GPU): same shuffles, every batch
+    split over the ranks, gradients averaged -- the run lands where the single-process run does (validation PSNR)."""
+    import json, os, socket, subprocess, sys
+    from nerf_few_shot_limitations_amd import train_cli
+    root = str(tmp_path / "scene")
+    _write_scene(root)
+    cfg = tmp_path / "cfg.yaml"
+    cfg.write_text(_CFG.format(dino="false", pf=10))
+    p = dict(O.make_weights("v2", 1, "fog"))
+    p["pos_encoder.freq_bands"] = 2.0 ** torch.linspace(0., 9, 10)
+    p["dir_encoder.freq_bands"] = 2.0 ** torch.linspace(0., 3, 4)
+    torch.save({"epoch": 0, "nerf_model_state_dict": p}, str(tmp_path / "init.pth"))
+    common = ["--config", str(cfg), "--data", root, "--mode", "f32", "--epochs", "2", "--checkpoint", str(tmp_path / "init.pth")]
+    one = train_cli.main(common + ["--out", str(tmp_path / "one")])
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NERF_TRAIN_BACKEND="gloo", NERF_TRAIN_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "nerf_few_shot_limitations_amd.train_cli"] + common + ["--out", str(tmp_path / "two"), "--data-parallel"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=repo, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    two = json.load(open(tmp_path / "two" / "train_log.json"))
+    assert [e["epoch"] for e in two] == [1, 2]
+    # the first epoch's mean loss: rank 0 reports the mean over ITS half of every batch -- compare the validation metric and
+    # the trained weights instead, which are common to all ranks
+    assert abs(two[-1]["psnr"] - one[-1]["psnr"]) < 0.05
+    a = torch.load(tmp_path / "one" / "best_tiny.pth", map_location="cpu", weights_only=True)["nerf_model_state_dict"]
+    b = torch.load(tmp_path / "two" / "best_tiny.pth", map_location="cpu", weights_only=True)["nerf_model_state_dict"]
+    worst = max(float((a[k] - b[k]).abs().max()) for k in a if k.endswith("weight"))
+    # not the same trajectory bit for bit: the stratified jitter is keyed by a ray's position inside the call, which differs
+    # between a whole batch and a rank's shard of it; bounded by what Adam can move in 8 steps
+    assert worst < 2.5 * 2e-3 * 8

@@ -32,12 +32,11 @@ class FlatParams:
         self.module = module
         self.flat = None
         self.offsets = []
-        self._params = None
 
     def params(self):
-        if self._params is None:                  # nn.Parameter objects are stable (only their storage is re-homed)
-            self._params = [p for m in self.module.linears() for p in (m.weight, m.bias)]
-        return self._params
+        # looked up on every call: Module.to() across device types REPLACES the nn.Parameter objects (a cached list would keep
+        # feeding the old ones to autograd); the registry dicts are read directly, nn.Module.__getattr__ is the slow path
+        return [m._parameters[k] for m in self.module.linears() for k in ("weight", "bias")]
 
     def ensure(self):
         ps = self.params()
@@ -82,12 +81,17 @@ def _grad_target(module):
         fg = module._flat_grad = torch.zeros_like(flat)
         module._flat_grad_views = fp.views(fg)
     grads = [p.grad for p in ps]
+    base = fg.data_ptr()
     if all(g is None for g in grads):
         fg.zero_()
-        for p, v in zip(ps, module._flat_grad_views):
+        # the view objects handed out earlier ARE the old .grad tensors: Module.to() re-homes a parameter's .grad in place
+        # (same Python object, new storage), after which they no longer alias the flat vector -- check before re-use
+        views = module._flat_grad_views
+        if any(v.data_ptr() != base + 4 * off for v, off in zip(views, fp.offsets)):
+            views = module._flat_grad_views = fp.views(fg)
+        for p, v in zip(ps, views):
             p.grad = v
         return fg
-    base = fg.data_ptr()
     if all(g is not None and g.data_ptr() == base + 4 * off and g.shape == p.shape for g, p, off in zip(grads, ps, fp.offsets)):
         return fg
     return None

@@ -959,3 +959,28 @@ def test_train_cli_data_parallel_matches_one_process(N, tmp_path):
     # not the same trajectory bit for bit: the stratified jitter is keyed by a ray's position inside the call, which differs
     # between a whole batch and a rank's shard of it; bounded by what Adam can move in 8 steps
     assert worst < 2.5 * 2e-3 * 8
+
+
+def test_training_survives_moving_the_module_and_loading_weights(N):
+    """`.cpu().cuda()` re-allocates every parameter (the flat vector loses them) and load_state_dict overwrites them in
+    place: in both cases the next backward must see the current values, forward AND transposed streams."""
+    x, g = inputs(2000, seed=71)
+    xd, gd = x.cuda(), g.cuda()
+
+    def grads(model):
+        for q in model.parameters():
+            q.grad = None
+        (model(xd) * gd).sum().backward()
+        return torch.cat([q.grad.reshape(-1) for q in model.parameters()]).clone()
+
+    ref, _ = make_model(N, "f32", scene="solid")
+    want = grads(ref)
+    m, _ = make_model(N, "f32", scene="fog")
+    grads(m)                                                   # training state built on the fog weights
+    m = m.cpu().cuda()                                         # new storages
+    m.load_state_dict(O.make_weights("v1", 0, "solid"))        # new values, in place
+    got = grads(m.train())
+    assert rel_to_max(got, want) < 1e-6
+    m.load_state_dict(O.make_weights("v1", 0, "fog"))
+    fog, _ = make_model(N, "f32", scene="fog")
+    assert rel_to_max(grads(m), grads(fog)) < 1e-6

@@ -984,3 +984,40 @@ def test_training_survives_moving_the_module_and_loading_weights(N):
     m.load_state_dict(O.make_weights("v1", 0, "fog"))
     fog, _ = make_model(N, "f32", scene="fog")
     assert rel_to_max(grads(m), grads(fog)) < 1e-6
+
+
+def test_autograd_route_follows_torch_gradient_conventions(N):
+    """What a reference-style loop may do around backward(): accumulate micro-batches, zero gradients in place instead of
+    dropping them, clip them -- all on the flat gradient vector behind .grad."""
+    x, g = inputs(3000, seed=81)
+    xd, gd = x.cuda(), g.cuda()
+    model, _ = make_model(N, "f32", scene="solid")
+
+    def flat_grad():
+        return torch.cat([q.grad.reshape(-1) for q in model.parameters()]).clone()
+
+    for q in model.parameters():
+        q.grad = None
+    (model(xd) * gd).sum().backward()
+    whole = flat_grad()
+    # two micro-batches accumulate (no zero_grad in between)
+    for q in model.parameters():
+        q.grad = None
+    (model(xd[:1000]) * gd[:1000]).sum().backward()
+    (model(xd[1000:]) * gd[1000:]).sum().backward()
+    assert rel_to_max(flat_grad(), whole) < 1e-5
+    # zero_grad(set_to_none=False) keeps the tensors: the next backward adds into zeros
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)
+    opt.zero_grad(set_to_none=False)
+    assert float(flat_grad().abs().max()) == 0.0
+    (model(xd) * gd).sum().backward()
+    assert torch.equal(flat_grad(), whole)                              # deterministic reduction: the same bits
+    # clipping scales the flat vector through its views; training.Adam then consumes that very vector
+    from nerf_few_shot_limitations_amd.training import Adam
+    total = torch.nn.utils.clip_grad_norm_(model.parameters(), 1.0)
+    assert abs(float(total) - float(whole.norm())) < 1e-3 * float(whole.norm())
+    assert abs(float(model._flat_grad.norm()) - 1.0) < 1e-3
+    before = model.flat_params().flat.clone()
+    Adam(model, lr=1e-3).step()
+    moved = (model.flat_params().flat - before).abs()
+    assert 0.5e-3 < float(moved.max()) <= 1.01e-3                      # first Adam step: lr * sign(g) where g is not ~0

@@ -204,6 +204,22 @@ class NeRFMLP(nn.Module):
         self._packed, self._packed_modes = ver, None
         return self._handle
 
+    # native state never travels with a copy: copy.deepcopy / pickle of a module that has rendered or trained would otherwise
+    # duplicate the nrf_model* (freed twice) and alias the flat vectors
+    _NATIVE = ("_handle", "_handle_dev", "_packed", "_packed_modes", "_flat", "_flat_grad", "_flat_grad_views", "_linears_cache", "_train_ready")
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in self._NATIVE:
+            st.pop(k, None)
+        return st
+
+    def __setstate__(self, st):
+        super().__setstate__(st)
+        self._handle = self._handle_dev = self._packed = self._packed_modes = self._flat = None
+        self._train_ready = False
+        self.__dict__.setdefault("_gen", 0)
+
     def release(self):
         if getattr(self, "_handle", None) is not None:
             L.lib().nrf_model_destroy(self._handle)

@@ -1021,3 +1021,26 @@ def test_autograd_route_follows_torch_gradient_conventions(N):
     Adam(model, lr=1e-3).step()
     moved = (model.flat_params().flat - before).abs()
     assert 0.5e-3 < float(moved.max()) <= 1.01e-3                      # first Adam step: lr * sign(g) where g is not ~0
+
+
+def test_deepcopy_of_a_trained_module_is_independent(N):
+    """copy.deepcopy (EMA / best-model snapshots) must not share the native handle or the flat vectors."""
+    import copy, gc
+    x, g = inputs(1000, seed=91)
+    xd, gd = x.cuda(), g.cuda()
+    a, _ = make_model(N, "f32", scene="solid")
+    (a(xd) * gd).sum().backward()
+    want = torch.cat([q.grad.reshape(-1) for q in a.parameters()]).clone()
+    b = copy.deepcopy(a)
+    assert b._handle is None and b._flat is None
+    with torch.no_grad():
+        for q in a.parameters():
+            q.mul_(0.5)                                            # a moves on; b keeps the snapshot
+    for q in b.parameters():
+        q.grad = None
+    (b(xd) * gd).sum().backward()
+    got = torch.cat([q.grad.reshape(-1) for q in b.parameters()])
+    assert rel_to_max(got, want) < 1e-6
+    assert a._handle is not None and b._handle is not None and a._handle.value != b._handle.value
+    del a, b
+    gc.collect()                                                   # two handles, two destroys

@@ -7,7 +7,9 @@
   * `composite`      nerf_mlp.VolumeRenderer / volume_render_radiance with grad enabled;
   * `FlatParams`     the module's parameters as views into one flat fp32 vector, so that an
                      optimizer step is visible to the kernels without leaving the device;
-  * `Adam`           torch.optim.Adam's update as one kernel on the flat vectors (train.py:113-118).
+  * `Adam`           torch.optim.Adam's update as one kernel on the flat vectors (train.py:113-118);
+  * `FusedStep`      the whole optimisation step of the reference's loop as a fixed sequence of library calls;
+  * `all_reduce_gradients`   data-parallel training: ONE collective per step on the flat gradient vector.
 
 There is no PyTorch fallback: without libnerfhip.so / a gfx950 GPU every call raises.
 """

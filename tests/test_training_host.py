@@ -10,7 +10,6 @@ import torch.nn.functional as F
 
 from oracle import nerf_oracle as O
 from tests import mfma_emulator as E
-from tests.test_packing_emulation import _encode_tiles
 
 
 @pytest.fixture(scope="module")

@@ -179,6 +179,10 @@ int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, in
 /* ray_utils.py:176-210 + dino_feature_model.py:114-148: points (N,3) -> features (N,C); xy (N,2) may be NULL. */
 int nrf_project_fetch(const nrf_dino* dino, const float* points, int64_t n, float* feats, float* xy, void* stream);
 
+/* dino_feature_model.py:114-148 on its own (== lora_dino.py:110-144, multi_scale_dino.py:156-183): bilinear grid_sample
+ * (zeros padding, align_corners=False) of a (1,Hp,Wp,C) channel-last map at n normalised image points (n,2) -> (n,C). */
+int nrf_sample_features(const float* features, int Hp, int Wp, int C, const float* points_2d, int64_t n, float* feats, void* stream);
+
 /* ---- host-only introspection (no GPU needed; used by the CPU test-suite to replay the
  *      kernel's MFMA walk over the packed stream) -------------------------------- */
 /* Packs `linears` exactly as nrf_model_create would for `mma_mode`.  stream_out / bias_out may be

@@ -15,10 +15,11 @@ from .config import load_config, resolve_near_far, model_from_config, render_set
 from .data_loader import load_blender_data
 from .evaluation import psnr, ssim, save_png, evaluate_views, evaluate_config
 from .training import Adam, FusedStep, all_reduce_gradients
+from .dino_features import project_points_to_image, sample_features_at_points
 
 __all__ = ["get_rays", "sample_points_along_rays", "hierarchical_sampling", "sample_pdf", "get_ray_batch",
            "PositionalEncoding", "NeRFMLP", "load_checkpoint_into", "VolumeRenderer", "volume_render_radiance",
            "render_rays", "render_camera", "render_hierarchical", "NeRFRenderer", "make_dino",
            "load_config", "resolve_near_far", "model_from_config", "render_settings",
            "load_blender_data", "psnr", "ssim", "save_png", "evaluate_views", "evaluate_config",
-           "Adam", "FusedStep", "all_reduce_gradients"]
+           "Adam", "FusedStep", "all_reduce_gradients", "project_points_to_image", "sample_features_at_points"]

@@ -74,6 +74,7 @@ SIGNATURES = {
     "nrf_debug_pack": (C.c_int, [C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "nrf_project_fetch": (C.c_int, [C.POINTER(nrf_dino), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_sample_features": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nrf_debug_pack_backward": (C.c_int, [C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int, C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "nrf_debug_train_plan": (C.c_int, [C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     # training path

@@ -629,6 +629,14 @@ int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear
     return NRF_OK;
 }
 
+int nrf_sample_features(const float* features, int Hp, int Wp, int C, const float* points_2d, int64_t n, float* feats, void* stream) {
+    if (n < 0 || Hp < 1 || Wp < 1 || C < 1) return fail(NRF_EINVAL, "bad sizes");
+    if (n == 0) return NRF_OK;
+    if (!features || !points_2d || !feats) return fail(NRF_EINVAL, "null pointer");
+    const int r = nrf::launch_sample_features(features, Hp, Wp, C, points_2d, n, feats, (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "sample_features launch failed");
+}
+
 int nrf_debug_pack_backward(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int mma_mode, uint8_t* stream_out, int64_t stream_cap,
                             int64_t* stream_bytes) {
     if (!arch || !linears || n_linear <= 0) return fail(NRF_EINVAL, "nrf_debug_pack_backward: null argument");

@@ -124,5 +124,6 @@ int launch_composite(const float* rgb, int rgb_stride, const float* sigma, int s
 int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, float* samples,
                       float* z_union, hipStream_t s);
 int launch_project_fetch(const DinoDev& d, const float* points, int64_t n, float* feats, float* xy, hipStream_t s);
+int launch_sample_features(const float* features, int Hp, int Wp, int C, const float* points_2d, int64_t n, float* feats, hipStream_t s);
 
 }  // namespace nrf

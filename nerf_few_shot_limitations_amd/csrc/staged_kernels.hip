@@ -311,15 +311,21 @@ __device__ __forceinline__ void project_point(const DinoDev& d, const float p[3]
     yn = y / (float)d.H * 2.0f - 1.0f;
 }
 
+// points2d: `points` already are normalised image coordinates (n,2) (sample_features_at_points on its own,
+// dino_feature_model.py:114-148); otherwise world points (n,3) projected into the source view first
 __global__ void __launch_bounds__(kBlock) project_fetch_kernel(DinoDev d, const float* __restrict__ points, int64_t n, float* __restrict__ feats,
-                                                               float* __restrict__ xy) {
+                                                               float* __restrict__ xy, int points2d) {
     const int64_t total = n * d.C;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
         const int64_t pi = i / d.C;
         const int ch = (int)(i - pi * d.C);
-        const float p[3] = {points[pi * 3], points[pi * 3 + 1], points[pi * 3 + 2]};
         float xn, yn;
-        project_point(d, p, xn, yn);
+        if (points2d) {
+            xn = points[pi * 2]; yn = points[pi * 2 + 1];
+        } else {
+            const float p[3] = {points[pi * 3], points[pi * 3 + 1], points[pi * 3 + 2]};
+            project_point(d, p, xn, yn);
+        }
         if (xy && ch == 0) { xy[pi * 2] = xn; xy[pi * 2 + 1] = yn; }
         // grid_sample, bilinear, zeros padding, align_corners=False
         const float gx = ((xn + 1.0f) * (float)d.Wp - 1.0f) * 0.5f;
@@ -424,7 +430,15 @@ int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int
 
 int launch_project_fetch(const DinoDev& d, const float* points, int64_t n, float* feats, float* xy, hipStream_t s) {
     if (n <= 0) return NRF_OK;
-    hipLaunchKernelGGL(project_fetch_kernel, dim3(grid_for(n * d.C, kBlock, 8192)), dim3(kBlock), 0, s, d, points, n, feats, xy);
+    hipLaunchKernelGGL(project_fetch_kernel, dim3(grid_for(n * d.C, kBlock, 8192)), dim3(kBlock), 0, s, d, points, n, feats, xy, 0);
+    return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
+}
+
+int launch_sample_features(const float* features, int Hp, int Wp, int C, const float* points_2d, int64_t n, float* feats, hipStream_t s) {
+    if (n <= 0) return NRF_OK;
+    DinoDev d{};
+    d.features = features; d.Hp = Hp; d.Wp = Wp; d.C = C;
+    hipLaunchKernelGGL(project_fetch_kernel, dim3(grid_for(n * C, kBlock, 8192)), dim3(kBlock), 0, s, d, points_2d, n, feats, (float*)nullptr, 1);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 

@@ -720,3 +720,26 @@ def test_project_fetch_golden(N, golden):
     assert np.all(np.abs(xy.cpu().numpy() - ref_xy) <= 2e-4 * (1 + np.abs(ref_xy)))
     ofe = O.sample_features_at_points(T(g["features"]), xy.cpu())
     assert maxdiff(feats, ofe) <= 1e-5
+
+
+def test_dino_side_channel_drop_ins(N, golden):
+    """project_points_to_image + sample_features_at_points as train.py:203-214 calls them, against the golden vectors captured
+    from the reference's own functions and the oracle."""
+    g = golden("dino_fetch")
+    pts, pose, fm = T(g["points"]), T(g["pose"]), T(g["features"])
+    xy, depth, mask = N.project_points_to_image(pts.cuda(), pose, float(g["focal"]), int(g["H"]), int(g["W"]))
+    ref_xy = g["xy"].astype(np.float64)
+    assert np.all(np.abs(xy.cpu().numpy() - ref_xy) <= 2e-4 * (1 + np.abs(ref_xy)))
+    oxy, odepth, omask = O.project_points_to_image(pts, pose, float(g["focal"]), int(g["H"]), int(g["W"]))
+    assert maxdiff(depth, odepth) <= 1e-5 and bool((mask.cpu() == omask).all())
+    # sampling on its own: at the reference's projections, compared with the oracle's grid_sample restatement
+    feats = N.sample_features_at_points(fm.cuda(), T(g["xy"]).float().cuda())
+    assert feats.shape == (pts.shape[0], fm.shape[-1])
+    assert maxdiff(feats, O.sample_features_at_points(fm, T(g["xy"]).float())) <= 1e-5
+    assert maxdiff(feats, g["sampled"]) <= 1e-5                         # the reference's own sample_features_at_points at its own projections
+    assert maxdiff(depth, g["depth"]) <= 1e-5 and np.array_equal(mask.cpu().numpy(), g["mask"].astype(bool))
+    inside = N.sample_features_at_points(fm.cuda(), T(g["xy_in"]).float().cuda())
+    assert maxdiff(inside, g["sampled_in"]) <= 1e-5
+    # a batch of maps
+    two = N.sample_features_at_points(torch.cat([fm, 2 * fm]).cuda(), T(g["xy"]).float().cuda())
+    assert two.shape[0] == 2 and torch.allclose(two[1], 2 * two[0], atol=1e-6)

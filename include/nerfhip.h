@@ -227,11 +227,17 @@ int64_t nrf_param_count(const nrf_model* m);
 
 /* Replaces nrf_model_update for device-resident parameters: re-packs the
  * forward (and, once training has been used, backward) streams of the modes in
- * mode_mask (bit NRF_MMA_*) from flat_params.  Enqueued on `stream`. */
+ * mode_mask (bit NRF_MMA_*) from flat_params, plus the bias table.  Enqueued on
+ * `stream`; a single mode is one kernel launch.  The streams of the modes NOT in the
+ * mask keep the previous parameters (a later render / backward in such a mode needs
+ * its own update; nrf_mlp_backward* refuses stale backward weights). */
 int nrf_model_update_device(nrf_model* m, const float* flat_params, int mode_mask, void* stream);
 
 /* Bytes of saved tensors ("context") a forward_train/backward pair needs for n
- * samples; the caller allocates it (device) and keeps it until backward ran. */
+ * samples; the caller allocates it (device) and keeps it until backward ran.  It holds
+ * the saved operand tiles of every layer, the ReLU bit planes, (V3) the softmax gate and
+ * the weight-gradient partial sums: about 9 KiB per sample for the 8x256 network in the
+ * 16-bit modes plus ~64 MiB of partial sums. */
 int64_t nrf_train_context_bytes(nrf_model* m, int mma_mode, int64_t n);
 
 /* nerf_model.py:16-24 forward with grad enabled: out4 as nrf_mlp_forward_v1,

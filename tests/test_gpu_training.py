@@ -1044,3 +1044,30 @@ def test_deepcopy_of_a_trained_module_is_independent(N):
     assert a._handle is not None and b._handle is not None and a._handle.value != b._handle.value
     del a, b
     gc.collect()                                                   # two handles, two destroys
+
+
+def test_fused_step_white_background_and_loss_weight(N):
+    """rendering.white_bkgd and loss.rgb_weight of the YAML reach both routes the same way (train.py:236, :41)."""
+    from nerf_few_shot_limitations_amd.training import Adam, FusedStep
+    R, S, steps = 128, 24, 3
+    z = torch.sort(torch.from_numpy(O.uniform01(131, R * S).reshape(R, S) * 4 + 2).float(), dim=-1).values.cuda()
+    rd = torch.from_numpy(O.uniform01(132, R * 3).reshape(R, 3) - 0.5).float().cuda()
+    tgt = torch.from_numpy(O.uniform01(133, R * 3).reshape(R, 3)).float().cuda()
+    pts = torch.from_numpy(O.uniform01(134, R * S * 3).reshape(R * S, 3) * 4 - 2).float().cuda()
+    dirs = rd[:, None, :].expand(R, S, 3).reshape(-1, 3).contiguous()
+    a, _ = make_v2(N, "f32", scene="fog")
+    b, _ = make_v2(N, "f32", scene="fog")
+    opt = Adam(a, lr=5e-4)
+    vr = N.VolumeRenderer()
+    ref = []
+    for _ in range(steps):
+        opt.zero_grad()
+        c, sg = a(pts, dirs, None)
+        pred = vr(c.view(R, S, 3), sg.view(R, S, 1), z, rd, white_bkgd=True)[0]
+        loss = 0.5 * torch.nn.functional.mse_loss(pred, tgt)
+        loss.backward()
+        opt.step()
+        ref.append(loss.item())
+    step = FusedStep(b, lr=5e-4, rgb_weight=0.5, white_bkgd=True)
+    got = [step(pts, z, rd, tgt, dirs=dirs).item() for _ in range(steps)]
+    assert np.allclose(ref, got, rtol=1e-5, atol=1e-7), (ref, got)

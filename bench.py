@@ -31,7 +31,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
+PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x3": 2500.0}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
 
 
 def training_line(N, args, dev):
@@ -82,7 +82,7 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32", "f16x3"])
     ap.add_argument("--net", default="v1", choices=["v1", "v2", "v3"])
     ap.add_argument("--scene", default="solid", choices=["fog", "solid", "smooth"])
     ap.add_argument("--ert", type=float, default=0.0)

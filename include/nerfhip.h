@@ -46,6 +46,9 @@ extern "C" {
 #define NRF_MMA_BF16 0  /* v_mfma_f32_32x32x16_bf16: weights + activations rounded to bf16 (throughput mode) */
 #define NRF_MMA_F16  1  /* v_mfma_f32_32x32x16_f16 : same rate, 3 more mantissa bits                          */
 #define NRF_MMA_F32  2  /* v_mfma_f32_32x32x2_f32  : exact fp32 fma chain (parity mode, 1/16 rate)           */
+#define NRF_MMA_F16X3 3 /* split f16: x = hi + lo (22 bits), W_hi X_hi + W_hi X_lo + W_lo X_hi as three 32x32x16 MFMAs: fp32-class
+                           results (meets the 1e-4 bar of the fp32 mode) at up to 1/3 of the 16-bit rate.  Inference entry
+                           points only (render / mlp_forward); operands must lie within the f16 range (|x| <= 65504)       */
 
 typedef struct nrf_model nrf_model;
 
@@ -103,7 +106,7 @@ typedef struct nrf_render_opts {
 
 /* ---- model handle -------------------------------------------------------- */
 
-/* Build the device-side packed weight streams (all three NRF_MMA_* modes) for
+/* Build the device-side packed weight streams (all NRF_MMA_* modes) for
  * `arch` from `n_linear` host Linear layers.  Replaces: module construction +
  * .to(device), train.py:82-89 / nerf_model.py:6-14. */
 int nrf_model_create(nrf_model** out, int device, const nrf_arch* arch,

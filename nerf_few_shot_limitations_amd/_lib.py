@@ -15,7 +15,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NRF_LIB") or os.path.join(_PKG, "libnerfhip.so")     # NRF_LIB: A/B another build of the same ABI
 
 NRF_NET_V1, NRF_NET_V2, NRF_NET_V3 = 1, 2, 3
-MMA_MODES = {"bf16": 0, "f16": 1, "f32": 2}
+MMA_MODES = {"bf16": 0, "f16": 1, "f32": 2, "f16x3": 3}
+# the training kernels are built for the first three; a module in the split mode (fp32-class results) trains in exact fp32
+TRAIN_MODE = {"bf16": "bf16", "f16": "f16", "f32": "f32", "f16x3": "f32"}
 ERRORS = {-1: "NRF_EINVAL", -2: "NRF_EUNSUPPORTED", -3: "NRF_EHIP", -4: "NRF_ENOMEM"}
 
 c_float_p = C.POINTER(C.c_float)
@@ -47,7 +49,7 @@ class nrf_render_opts(C.Structure):
                 ("white_bkgd", C.c_int32), ("mma_mode", C.c_int32), ("dino", C.POINTER(nrf_dino))]
 
 
-# name -> (restype, argtypes); this table is also what tests/test_cabi.py checks against include/nerfhip.h
+# name -> (restype, argtypes); tests/test_packing_emulation.py checks this table against include/nerfhip.h
 SIGNATURES = {
     "nrf_abi_version": (C.c_int, []),
     "nrf_last_error": (C.c_char_p, []),

@@ -89,9 +89,9 @@ struct nrf_model {
     int device = 0;
     nrf::NetPlan plan;
     std::vector<nrf::HostLinear> lin;
-    nrf::PackedStream h_stream[3];
+    nrf::PackedStream h_stream[nrf::kModes];
     std::vector<float> h_bias;
-    void* d_stream[3] = {nullptr, nullptr, nullptr};
+    void* d_stream[nrf::kModes] = {nullptr, nullptr, nullptr, nullptr};
     float* d_bias = nullptr;
     unsigned long long* d_queues = nullptr;
     nrf::DeviceNet net{};
@@ -105,15 +105,15 @@ struct nrf_model {
     nrf::TrainDev train{};
     void* d_bstream[3] = {nullptr, nullptr, nullptr};
     int32_t* d_maps = nullptr;
-    int32_t* d_src[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [forward|backward][16-bit|fp32] element sources
-    int64_t n_src[2][2] = {{0, 0}, {0, 0}};
+    int32_t* d_src[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // [forward|backward][packing.hpp stream kind] element sources
+    int64_t n_src[2][3] = {{0, 0, 0}, {0, 0, 0}};                                        // (no backward stream in the split mode)
     int32_t* d_bias_src = nullptr;
 };
 
 namespace {
 
 int upload(nrf_model* m, hipStream_t s, bool allocate) {
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < nrf::kModes; ++mode) {
         m->h_stream[mode] = nrf::pack_stream(m->plan, m->lin, mode);
         const size_t bytes = m->h_stream[mode].bytes.size();
         if (allocate) NRF_HIP(hipMalloc(&m->d_stream[mode], bytes));
@@ -148,11 +148,11 @@ int upload(nrf_model* m, hipStream_t s, bool allocate) {
 int ensure_sources(nrf_model* m) {
     if (m->d_src[0][0]) return NRF_OK;
     m->layout = nrf::param_layout(m->lin);
-    for (int f32 = 0; f32 < 2; ++f32) {
-        const std::vector<int32_t> src = nrf::stream_sources(m->plan, m->layout, f32 != 0);
-        NRF_HIP(hipMalloc((void**)&m->d_src[0][f32], src.size() * sizeof(int32_t)));
-        NRF_HIP(hipMemcpy(m->d_src[0][f32], src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        m->n_src[0][f32] = (int64_t)src.size();
+    for (int kind = 0; kind < 3; ++kind) {
+        const std::vector<int32_t> src = nrf::stream_sources(m->plan, m->layout, kind);
+        NRF_HIP(hipMalloc((void**)&m->d_src[0][kind], src.size() * sizeof(int32_t)));
+        NRF_HIP(hipMemcpy(m->d_src[0][kind], src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        m->n_src[0][kind] = (int64_t)src.size();
     }
     const std::vector<int32_t> bsrc = nrf::bias_sources(m->plan, m->layout);
     NRF_HIP(hipMalloc((void**)&m->d_bias_src, bsrc.size() * sizeof(int32_t)));
@@ -179,7 +179,7 @@ int ensure_train(nrf_model* m) {
         m->bfresh[mode] = !m->lin_stale;
     }
     for (int f32 = 0; f32 < 2; ++f32) {
-        const std::vector<int32_t> src = nrf::stream_sources(m->bplan, m->layout, f32 != 0);
+        const std::vector<int32_t> src = nrf::stream_sources(m->bplan, m->layout, f32);
         NRF_HIP(hipMalloc((void**)&m->d_src[1][f32], src.size() * sizeof(int32_t)));
         NRF_HIP(hipMemcpy(m->d_src[1][f32], src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         m->n_src[1][f32] = (int64_t)src.size();
@@ -212,7 +212,7 @@ int check_opts(const nrf_render_opts* o) {
     if (!o) return fail(NRF_EINVAL, "opts is NULL");
     if (o->n_samples < 1 || o->n_samples > 4096) return fail(NRF_EINVAL, "n_samples must be in 1..4096");
     if (!(o->near > 0.0f) || !(o->far > o->near) || !std::isfinite(o->far)) return fail(NRF_EINVAL, "need 0 < near < far");
-    if (o->mma_mode < 0 || o->mma_mode > 2) return fail(NRF_EINVAL, "unknown mma_mode");
+    if (o->mma_mode < 0 || o->mma_mode >= nrf::kModes) return fail(NRF_EINVAL, "unknown mma_mode");
     if (!(o->ert_eps >= 0.0f) || o->ert_eps >= 1.0f) return fail(NRF_EINVAL, "ert_eps must be in [0,1)");
     return NRF_OK;
 }
@@ -287,14 +287,14 @@ int nrf_model_update(nrf_model* m, const nrf_linear* linears, int n_linear, void
 void nrf_model_destroy(nrf_model* m) {
     if (!m) return;
     DeviceGuard guard(m->device);
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < nrf::kModes; ++i)
         if (m->d_stream[i]) (void)hipFree(m->d_stream[i]);
     if (m->d_bias) (void)hipFree(m->d_bias);
     if (m->d_queues) (void)hipFree(m->d_queues);
     for (int i = 0; i < 3; ++i)
         if (m->d_bstream[i]) (void)hipFree(m->d_bstream[i]);
     for (int i = 0; i < 2; ++i)
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 3; ++j)
             if (m->d_src[i][j]) (void)hipFree(m->d_src[i][j]);
     if (m->d_maps) (void)hipFree(m->d_maps);
     if (m->d_bias_src) (void)hipFree(m->d_bias_src);
@@ -446,33 +446,36 @@ int64_t nrf_param_count(const nrf_model* m) {
 
 int nrf_model_update_device(nrf_model* m, const float* flat_params, int mode_mask, void* stream) {
     if (!m || !flat_params) return fail(NRF_EINVAL, "nrf_model_update_device: null argument");
-    if (mode_mask <= 0 || mode_mask > 7) return fail(NRF_EINVAL, "mode_mask must select at least one of the three modes");
+    if (mode_mask <= 0 || mode_mask >= (1 << nrf::kModes)) return fail(NRF_EINVAL, "mode_mask must select at least one of the NRF_MMA_* modes");
     DeviceGuard guard(m->device);
     if (!guard.ok) return fail(NRF_EHIP, "cannot select the model's device");
     int rc = ensure_sources(m);
     if (rc != NRF_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    if (mode_mask == 1 || mode_mask == 2 || mode_mask == 4) {
-        // the per-step case: one mode -> forward stream, backward stream (once training is set up) and bias table in one launch
-        const int mode = mode_mask == 1 ? 0 : (mode_mask == 2 ? 1 : 2);
-        const int f32 = mode == NRF_MMA_F32;
-        const int32_t* src[3] = {m->d_src[0][f32], m->train_ready ? m->d_src[1][f32] : nullptr, m->d_bias_src};
-        const int64_t n[3] = {m->n_src[0][f32], m->n_src[1][f32], m->plan.n_bias};
+    if ((mode_mask & (mode_mask - 1)) == 0) {
+        // the per-step case: one mode -> forward stream, backward stream (once training is set up; the split mode has none)
+        // and bias table in one launch
+        int mode = 0;
+        while (!(mode_mask & (1 << mode))) ++mode;
+        const int kind = nrf::stream_kind(mode);
+        const bool bwd = m->train_ready && mode < 3;
+        const int32_t* src[3] = {m->d_src[0][kind], bwd ? m->d_src[1][kind] : nullptr, m->d_bias_src};
+        const int64_t n[3] = {m->n_src[0][kind], bwd ? m->n_src[1][kind] : 0, m->plan.n_bias};
         const int modes[3] = {mode, mode, NRF_MMA_F32};
-        void* out[3] = {m->d_stream[mode], m->d_bstream[mode], m->d_bias};
+        void* out[3] = {m->d_stream[mode], bwd ? m->d_bstream[mode] : nullptr, m->d_bias};
         rc = nrf::launch_repack3(flat_params, src, n, modes, out, s);
         if (rc != NRF_OK) return fail(rc, "repack launch failed");
         m->lin_stale = true;
         for (int k = 0; k < 3; ++k) m->bfresh[k] = (k == mode) && m->train_ready;
         return NRF_OK;
     }
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < nrf::kModes; ++mode) {
         if (!(mode_mask & (1 << mode))) continue;
-        const int f32 = mode == NRF_MMA_F32;
-        rc = nrf::launch_repack(flat_params, m->d_src[0][f32], m->n_src[0][f32], mode, m->d_stream[mode], s);
+        const int kind = nrf::stream_kind(mode);
+        rc = nrf::launch_repack(flat_params, m->d_src[0][kind], m->n_src[0][kind], mode, m->d_stream[mode], s);
         if (rc != NRF_OK) return fail(rc, "repack launch failed");
-        if (m->train_ready) {
-            rc = nrf::launch_repack(flat_params, m->d_src[1][f32], m->n_src[1][f32], mode, m->d_bstream[mode], s);
+        if (m->train_ready && mode < 3) {
+            rc = nrf::launch_repack(flat_params, m->d_src[1][kind], m->n_src[1][kind], mode, m->d_bstream[mode], s);
             if (rc != NRF_OK) return fail(rc, "repack launch failed");
             m->bfresh[mode] = true;
         }
@@ -495,7 +498,7 @@ int64_t nrf_train_context_bytes(nrf_model* m, int mma_mode, int64_t n) {
 int nrf_mlp_forward_train_v1(nrf_model* m, int mma_mode, const float* x_enc, int64_t n, float* out4, void* ctx, int64_t ctx_bytes,
                              void* stream) {
     if (!m) return fail(NRF_EINVAL, "model is NULL");
-    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode (the training path is built for bf16, f16 and f32)");
     if (n == 0) return NRF_OK;
     if (!x_enc || !out4 || !ctx) return fail(NRF_EINVAL, "null pointer");
     DeviceGuard guard(m->device);
@@ -511,7 +514,7 @@ int nrf_mlp_forward_train_v1(nrf_model* m, int mma_mode, const float* x_enc, int
 int nrf_mlp_backward_v1(nrf_model* m, int mma_mode, const float* out4, const float* g_out4, int64_t n, void* ctx, int64_t ctx_bytes,
                         float* flat_grad, void* stream) {
     if (!m) return fail(NRF_EINVAL, "model is NULL");
-    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode (the training path is built for bf16, f16 and f32)");
     if (n == 0) return NRF_OK;
     if (!out4 || !g_out4 || !ctx || !flat_grad) return fail(NRF_EINVAL, "null pointer");
     DeviceGuard guard(m->device);
@@ -529,7 +532,7 @@ int nrf_mlp_backward_v1(nrf_model* m, int mma_mode, const float* out4, const flo
 int nrf_mlp_forward_train(nrf_model* m, int mma_mode, const float* positions, const float* directions, const float* dino, int64_t n, float* rgb,
                           float* density, void* ctx, int64_t ctx_bytes, void* stream) {
     if (!m) return fail(NRF_EINVAL, "model is NULL");
-    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode (the training path is built for bf16, f16 and f32)");
     if (n == 0) return NRF_OK;
     if (!positions || !directions || !rgb || !density || !ctx) return fail(NRF_EINVAL, "null pointer");
     if (m->arch.net == NRF_NET_V1) return fail(NRF_EINVAL, "V1 models take encoded inputs: nrf_mlp_forward_train_v1");
@@ -549,7 +552,7 @@ int nrf_mlp_forward_train(nrf_model* m, int mma_mode, const float* positions, co
 int nrf_mlp_backward(nrf_model* m, int mma_mode, const float* rgb, const float* density, const float* g_rgb, const float* g_density, int64_t n,
                      void* ctx, int64_t ctx_bytes, float* flat_grad, void* stream) {
     if (!m) return fail(NRF_EINVAL, "model is NULL");
-    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode");
+    if (n < 0 || mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "bad n / mma_mode (the training path is built for bf16, f16 and f32)");
     if (n == 0) return NRF_OK;
     if (!rgb || !density || !g_rgb || !g_density || !ctx || !flat_grad) return fail(NRF_EINVAL, "null pointer");
     if (m->arch.net == NRF_NET_V1) return fail(NRF_EINVAL, "V1 models: nrf_mlp_backward_v1");
@@ -609,7 +612,7 @@ int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, in
 int nrf_debug_pack(const nrf_arch* arch, const nrf_linear* linears, int n_linear, int mma_mode, uint8_t* stream_out, int64_t stream_cap,
                    int64_t* stream_bytes, float* bias_out, int64_t bias_cap, int64_t* n_bias) {
     if (!arch || !linears || n_linear <= 0) return fail(NRF_EINVAL, "nrf_debug_pack: null argument");
-    if (mma_mode < 0 || mma_mode > 2) return fail(NRF_EINVAL, "unknown mma_mode");
+    if (mma_mode < 0 || mma_mode >= nrf::kModes) return fail(NRF_EINVAL, "unknown mma_mode");
     std::string err;
     std::vector<nrf::HostLinear> lin;
     nrf::NetPlan plan;

@@ -664,7 +664,7 @@ int run_forward(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, s
 }
 
 bool check_net(const DeviceNet& net, int mode, std::string& err) {
-    if (mode < 0 || mode > 2) { err = "unknown mma_mode"; return false; }
+    if (mode < 0 || mode >= kModes) { err = "unknown mma_mode"; return false; }
     if (net.n_bias > kBiasMaxFloats) { err = "bias table exceeds the LDS carve-out"; return false; }
     if (net.arch.dir_freq != 4 && net.arch.net != NRF_NET_V1) { err = "only dir_freq=4 is built"; return false; }
     return true;
@@ -688,6 +688,7 @@ static bool wide_waves() {
         case NRF_MMA_F16:                                                                                   \
             if (wide_waves()) return FN<NET<ModeF16, 1, LP>, ModeF16, 1, 8, LP, 4>(__VA_ARGS__);           \
             return FN<NET<ModeF16, 2, LP>, ModeF16, 2, 4, LP, 4>(__VA_ARGS__);                              \
+        case NRF_MMA_F16X3: return FN<NET<ModeF16X3, 1, LP>, ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);         \
         default: return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                         \
     }
 
@@ -696,6 +697,7 @@ static bool wide_waves() {
     switch (mode) {                                                                                         \
         case NRF_MMA_BF16: return FN<NETT(ModeBF16), ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);                   \
         case NRF_MMA_F16:  return FN<NETT(ModeF16), ModeF16, 1, 8, LP, 4>(__VA_ARGS__);                     \
+        case NRF_MMA_F16X3: return FN<NETT(ModeF16X3), ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);              \
         default:           return FN<NETT(ModeF32), ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                     \
     }
 #define NRF_NET_V2_10(M) NetV2<M, 1, 10>

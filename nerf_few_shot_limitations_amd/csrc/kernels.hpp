@@ -11,12 +11,13 @@
 namespace nrf {
 
 constexpr int kMaxCams = 8;
+constexpr int kModes = 4;           // NRF_MMA_BF16, _F16, _F32, _F16X3 (the training path is built for the first three)
 
 // device-side image of one nrf_model
 struct DeviceNet {
     nrf_arch arch;
-    const void* stream[3];      // packed fragment streams, indexed by NRF_MMA_*
-    uint32_t n_chunks[3];
+    const void* stream[kModes];   // packed fragment streams, indexed by NRF_MMA_*
+    uint32_t n_chunks[kModes];
     const float* bias;          // bias table (fp32, shared by all modes)
     int n_bias;
     int64_t flops_per_sample;

@@ -142,7 +142,7 @@ struct Pipe {
 // ---------------------------------------------------------------------------
 struct ModeBF16 {
     static constexpr int SUB = 2;            // fragments per (m-tile, k-tile)
-    static constexpr bool FAST_TRIG = true;  // v_sin on exactly reduced turns: error far below bf16 resolution
+    static constexpr int TRIG = 1;           // v_sin on exactly reduced turns: error far below bf16 resolution (nets.hpp:encode3)
     static constexpr bool FAST_EXP = true;   // v_exp based exp/sigmoid in the compositor
     typedef bf16x8 frag_t;
     struct Act { bf16x8 f[2]; };
@@ -165,7 +165,7 @@ struct ModeBF16 {
 
 struct ModeF16 {
     static constexpr int SUB = 2;
-    static constexpr bool FAST_TRIG = true;
+    static constexpr int TRIG = 1;
     static constexpr bool FAST_EXP = false;
     typedef f16x8 frag_t;
     struct Act { f16x8 f[2]; };
@@ -188,7 +188,7 @@ struct ModeF16 {
 
 struct ModeF32 {
     static constexpr int SUB = 4;
-    static constexpr bool FAST_TRIG = false;
+    static constexpr int TRIG = 0;           // ocml sincosf on the exact argument
     static constexpr bool FAST_EXP = false;
     typedef f32x4 frag_t;
     struct Act { float r[16]; };
@@ -201,6 +201,52 @@ struct ModeF32 {
         Act o;
 #pragma unroll
         for (int r = 0; r < 16; ++r) o.r[r] = RELU ? fmaxf(v[r], 0.0f) : v[r];
+        return o;
+    }
+};
+
+
+// Split-precision f16 ("f16x3"): every operand is carried as hi + lo with hi = f16(x), lo = f16(x - hi) -- 22 significant
+// bits -- and a product is three MFMAs at the 32x32x16 rate: W_hi*X_hi + W_hi*X_lo + W_lo*X_hi (the dropped lo*lo term is
+// 2^-22 relative; every f16 x f16 product is exact in the fp32 accumulator).  This is the parity-grade FAST mode: fp32-class
+// results (1e-4 bar of BASELINE.json) at up to 1/3 of the 16-bit MFMA rate instead of the fp32 MFMA's 1/16.
+// The low parts of small values are f16 subnormals; gfx950 keeps them in the conversion and in the matrix core
+// (tools/f16_subnormal_probe.hip).  Operands are clamped to the f16 range (+-65504): activations beyond it would need bf16x3.
+// Stream: SUB = 4 fragments per (m-tile, k-tile) = [s0 hi, s0 lo, s1 hi, s1 lo] (packing.cpp); an even fragment (W_hi) feeds
+// two MFMAs (X_hi, X_lo), an odd one (W_lo) one (X_hi).  Activations take 16 registers per 32-feature tile, as in the fp32
+// mode, so the geometry is the fp32 mode's: 4 waves x 32 samples, one wave per SIMD.
+struct ModeF16X3 {
+    static constexpr int SUB = 4;
+    static constexpr int TRIG = 2;           // polynomial sin on exactly reduced turns: <= 2e-7 abs (nets.hpp:encode3)
+    static constexpr bool FAST_EXP = false;
+    typedef f16x8 frag_t;
+    struct Act { f16x8 hi[2], lo[2]; };
+    __device__ static __forceinline__ void mma(f32x16& acc, const frag_t& a, const Act& b, int q) {
+        const int s = q >> 1;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.hi[s], acc, 0, 0, 0);
+        if (!(q & 1)) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b.lo[s], acc, 0, 0, 0);
+    }
+    template <bool RELU>
+    __device__ static __forceinline__ Act to_act(const f32x16& v) {
+        Act o;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            i32x4 wh, wl;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // v_med3_f32: ReLU and the f16 range clamp in one instruction
+                const float a = __builtin_amdgcn_fmed3f(v[8 * s + 2 * j], RELU ? 0.0f : -65504.0f, 65504.0f);
+                const float b = __builtin_amdgcn_fmed3f(v[8 * s + 2 * j + 1], RELU ? 0.0f : -65504.0f, 65504.0f);
+                const f32x2 ab = {a, b};
+                const f16x2 h = __builtin_convertvector(ab, f16x2);
+                const f32x2 hf = __builtin_convertvector(h, f32x2);
+                const f32x2 rest = {__fsub_rn(a, hf[0]), __fsub_rn(b, hf[1])};      // exact
+                wh[j] = __builtin_bit_cast(int, h);
+                wl[j] = __builtin_bit_cast(int, __builtin_convertvector(rest, f16x2));
+            }
+            o.hi[s] = __builtin_bit_cast(f16x8, wh);
+            o.lo[s] = __builtin_bit_cast(f16x8, wl);
+        }
         return o;
     }
 };

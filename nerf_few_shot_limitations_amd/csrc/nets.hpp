@@ -11,6 +11,30 @@ namespace nrf {
 constexpr float kInv2PiHi = 0x1.45f306p-3f;     // fl32(1/(2 pi))
 constexpr float kInv2PiLo = 0x1.b9391p-28f;     // 1/(2 pi) - kInv2PiHi
 
+// sin(2 pi v) for |v| <= 0.2512 turns: 2 pi v + v^3 Q(v^2), Q a degree-3 least-squares fit on Chebyshev nodes (fit error 7e-9);
+// with the leading coefficient split in two floats the fp32 evaluation stays within 1.5e-7 of the exact value.
+__device__ __forceinline__ float sin_turns_poly(float v) {
+    constexpr float k2PiHi = 0x1.921fb6p+2f, k2PiLo = -0x1.777a5cp-23f;      // 2 pi = hi + lo
+    const float w = __fmul_rn(v, v);
+    float q = 0x1.419126p+5f;
+    q = __builtin_fmaf(q, w, -0x1.328822p+6f);
+    q = __builtin_fmaf(q, w, 0x1.466ad6p+6f);
+    q = __builtin_fmaf(q, w, -0x1.4abbcep+5f);
+    const float t = __builtin_fmaf(q, w, k2PiLo);
+    return __builtin_fmaf(v, k2PiHi, __fmul_rn(v, t));
+}
+
+// sin (want_cos = 0) or cos (1) of 2 pi (g + small), g in [-0.5, 0.5] turns exactly reduced, `u` = g plus the low-order part of
+// the turn count: fold to [-0.25, 0.25] -- cos(2 pi u) = sin(2 pi (1/4 - |u|)); sin(2 pi u) = sgn(u) sin(2 pi min(|u|, 1/2 - |u|))
+// -- every subtraction of the fold is exact (Sterbenz) except 1/4 - |u| below 1/8, where it loses < 1e-8 turns.
+__device__ __forceinline__ float sin_or_cos_turns(float u, int want_cos) {
+    const float au = __builtin_fabsf(u);
+    const float vs = fminf(au, __fsub_rn(0.5f, au));
+    const float vsin = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, vs) ^ (__builtin_bit_cast(uint32_t, u) & 0x80000000u));
+    const float vcos = __fsub_rn(0.25f, au);
+    return sin_turns_poly(want_cos ? vcos : vsin);
+}
+
 __device__ __attribute__((noinline)) float precise_sin_or_cos(float arg, int want_cos) {
     float s, c;
     sincosf(arg, &s, &c);
@@ -26,7 +50,7 @@ __device__ __forceinline__ void encode3(const float p[3], int h, typename Mode::
     constexpr int KT = pe_tiles(L);
     f32x16 e[KT];
     float hi[3], lo[3];
-    if constexpr (Mode::FAST_TRIG) {
+    if constexpr (Mode::TRIG != 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             hi[c] = p[c] * kInv2PiHi;
@@ -41,10 +65,16 @@ __device__ __forceinline__ void encode3(const float p[3], int h, typename Mode::
         if constexpr (u < 3 * L) {
             constexpr int f = u / 3, c = u % 3;
             constexpr float scale = (float)(1u << f);
-            if constexpr (Mode::FAST_TRIG) {
+            if constexpr (Mode::TRIG == 1) {
                 // turns: fract() of the exact scaled high part + scaled low part; cos = sin a quarter turn on
                 const float rev = __builtin_fmaf(lo[c], scale, __builtin_amdgcn_fractf(hi[c] * scale)) + quarter;
                 v = __builtin_amdgcn_sinf(rev);
+            } else if constexpr (Mode::TRIG == 2) {
+                // parity-grade and cheap: the same exact reduction (the scaled high part minus its nearest integer is exact),
+                // then a polynomial instead of v_sin: <= 2e-7 abs for |x| <= 8 and every frequency up to 2^14
+                const float a = hi[c] * scale;
+                const float g = __fsub_rn(a, __builtin_rintf(a));
+                v = sin_or_cos_turns(__builtin_fmaf(lo[c], scale, g), h);
             } else {
                 v = precise_sin_or_cos(p[c] * scale, h);
             }

@@ -45,6 +45,27 @@ uint16_t f32_to_f16(float x) {                       // round to nearest even, s
     return (uint16_t)(sign | h);
 }
 
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t u;
+    if (e == 0) {
+        if (m == 0) { u = sign; }
+        else {                                         // subnormal: value = m * 2^-24
+            const float v = (float)m * 5.9604644775390625e-8f;
+            std::memcpy(&u, &v, 4);
+            u |= sign;
+        }
+    } else if (e == 31) {
+        u = sign | 0x7F800000u | (m << 13);
+    } else {
+        u = sign | ((e - 15 + 127) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+
 int expected_linears(const nrf_arch& a) {
     switch (a.net) {
         case NRF_NET_V1: return a.n_layers + 2;
@@ -241,8 +262,9 @@ int64_t element_source(const LayerPlan& L, const ParamLayout& lay, int r, int k)
 }
 }  // namespace
 
-std::vector<int32_t> stream_sources(const NetPlan& plan, const ParamLayout& lay, bool f32) {
-    const int SUB = f32 ? 4 : 2, n_el = f32 ? 4 : 8;
+std::vector<int32_t> stream_sources(const NetPlan& plan, const ParamLayout& lay, int kind) {
+    const bool f32 = kind == kStreamF32, x3 = kind == kStreamX3;
+    const int SUB = (f32 || x3) ? 4 : 2, n_el = f32 ? 4 : 8;
     size_t total_frags = 0;
     for (const auto& L : plan.layers) {
         const size_t f = (size_t)L.MT * L.KT * SUB;
@@ -257,8 +279,11 @@ std::vector<int32_t> stream_sources(const NetPlan& plan, const ParamLayout& lay,
                     for (int lane = 0; lane < 64; ++lane) {
                         const int i = lane & 31, h = lane >> 5;
                         for (int e = 0; e < n_el; ++e) {
+                            // split mode: fragments 2s' (hi parts) and 2s'+1 (lo parts) hold the same K indices as the 16-bit
+                            // fragment s' (mlp_core.hpp:ModeF16X3)
+                            const int s16 = x3 ? (s >> 1) : s;
                             const int k = f32 ? (32 * t + 8 * s + 4 * h + e)
-                                              : (32 * t + 16 * s + 8 * (e >> 2) + 4 * h + (e & 3));
+                                              : (32 * t + 16 * s16 + 8 * (e >> 2) + 4 * h + (e & 3));
                             src[(frag * 64 + lane) * n_el + e] = (int32_t)element_source(L, lay, 32 * m + i, k);
                         }
                     }
@@ -278,14 +303,14 @@ std::vector<int32_t> bias_sources(const NetPlan& plan, const ParamLayout& lay) {
 }
 
 PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin, int mode) {
-    const bool f32 = (mode == NRF_MMA_F32);
+    const bool f32 = (mode == NRF_MMA_F32), x3 = (mode == NRF_MMA_F16X3);
     const ParamLayout lay = param_layout(lin);
     std::vector<float> flat((size_t)lay.total);
     for (size_t i = 0; i < lin.size(); ++i) {
         std::memcpy(flat.data() + lay.w_off[i], lin[i].w.data(), lin[i].w.size() * sizeof(float));
         std::memcpy(flat.data() + lay.b_off[i], lin[i].b.data(), lin[i].b.size() * sizeof(float));
     }
-    const std::vector<int32_t> src = stream_sources(plan, lay, f32);
+    const std::vector<int32_t> src = stream_sources(plan, lay, stream_kind(mode));
     PackedStream out;
     const size_t per_frag = f32 ? 256 : 512;
     out.n_chunks = (uint32_t)(src.size() / per_frag / kChunkFrags);
@@ -294,6 +319,13 @@ PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin
         const float v = src[i] >= 0 ? flat[src[i]] : 0.0f;
         if (f32) {
             std::memcpy(out.bytes.data() + i * 4, &v, 4);
+        } else if (x3) {
+            // element i sits in fragment i/512; every layer starts on a chunk (16 fragments) boundary and holds its hi/lo
+            // fragments alternately, so the parity of the fragment index tells the part
+            const uint16_t hi = f32_to_f16(v);
+            uint16_t q = hi;
+            if ((i / per_frag) & 1) q = f32_to_f16(v - f16_to_f32(hi));      // v - hi is exact in fp32
+            std::memcpy(out.bytes.data() + i * 2, &q, 2);
         } else {
             const uint16_t q = (mode == NRF_MMA_BF16) ? f32_to_bf16(v) : f32_to_f16(v);
             std::memcpy(out.bytes.data() + i * 2, &q, 2);

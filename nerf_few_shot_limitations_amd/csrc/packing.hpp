@@ -54,7 +54,11 @@ bool make_backward_plan(const nrf_arch& arch, const std::vector<HostLinear>& lin
 // Where every element of a packed stream comes from: flat-parameter offset, -1 = zero.  Elements in stream
 // order (fragment, lane, element); 512 per fragment in the 16-bit modes, 256 in the fp32 mode.  The host packer
 // and the device re-packer (after every optimizer step) are both a gather through this table.
-std::vector<int32_t> stream_sources(const NetPlan& plan, const ParamLayout& lay, bool f32);
+// kind: kStream16 (bf16 / f16: 2 fragments of 8 elements per tile pair), kStreamF32 (4 fragments of 4 fp32), kStreamX3 (the split
+// f16 mode: 4 fragments of 8 -- hi and lo parts of the two 16-bit fragments, interleaved).
+enum { kStream16 = 0, kStreamF32 = 1, kStreamX3 = 2 };
+inline int stream_kind(int mma_mode) { return mma_mode == NRF_MMA_F32 ? kStreamF32 : (mma_mode == NRF_MMA_F16X3 ? kStreamX3 : kStream16); }
+std::vector<int32_t> stream_sources(const NetPlan& plan, const ParamLayout& lay, int kind);
 std::vector<int32_t> bias_sources(const NetPlan& plan, const ParamLayout& lay);
 
 // One weight-gradient job = one Linear (or the head pseudo-layer): dW[o][i] += sum_samples dZ[o] * X[i].
@@ -81,5 +85,6 @@ std::vector<float> pack_bias(const NetPlan& plan, const std::vector<HostLinear>&
 
 uint16_t f32_to_bf16(float x);
 uint16_t f32_to_f16(float x);
+float f16_to_f32(uint16_t h);
 
 }  // namespace nrf

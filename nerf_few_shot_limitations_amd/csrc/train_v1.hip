@@ -9,12 +9,24 @@ namespace nrf {
 // parameter re-pack and Adam
 // ---------------------------------------------------------------------------------------------
 // out element i = convert(flat[src[i]]) (0 where src < 0); mode selects the operand type
+// one 16-bit operand pair of the stream: bf16, f16, or the split mode's hi / lo part (pair i lies in fragment i/256; odd
+// fragments carry the low parts: packing.cpp:pack_stream)
+__device__ __forceinline__ uint32_t convert_pair(float a, float b, int mode, int64_t pair) {
+    if (mode == NRF_MMA_BF16) return (uint32_t)pack_pair<bf16x2, false>(a, b);
+    if (mode == NRF_MMA_F16X3 && ((pair >> 8) & 1)) {
+        const f32x2 ab = {a, b};
+        const f32x2 hf = __builtin_convertvector(__builtin_convertvector(ab, f16x2), f32x2);
+        return (uint32_t)pack_pair<f16x2, false>(__fsub_rn(a, hf[0]), __fsub_rn(b, hf[1]));
+    }
+    return (uint32_t)pack_pair<f16x2, false>(a, b);
+}
+
 __global__ void __launch_bounds__(256) repack16_kernel(const float* __restrict__ flat, const int32_t* __restrict__ src, int64_t n_pairs,
-                                                      int bf16, uint32_t* __restrict__ out) {
+                                                      int mode, uint32_t* __restrict__ out) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_pairs; i += (int64_t)gridDim.x * blockDim.x) {
         const int2 s = *(const int2*)(src + 2 * i);
         const float a = s.x >= 0 ? flat[s.x] : 0.0f, b = s.y >= 0 ? flat[s.y] : 0.0f;
-        out[i] = bf16 ? (uint32_t)pack_pair<bf16x2, false>(a, b) : (uint32_t)pack_pair<f16x2, false>(a, b);
+        out[i] = convert_pair(a, b, mode, i);
     }
 }
 
@@ -46,7 +58,7 @@ __global__ void __launch_bounds__(256) repack3_kernel(const float* __restrict__ 
         } else {
             const int2 sp = *(const int2*)(a.src[k] + 2 * j);
             const float x = sp.x >= 0 ? flat[sp.x] : 0.0f, y = sp.y >= 0 ? flat[sp.y] : 0.0f;
-            ((uint32_t*)a.out[k])[j] = a.mode[k] == NRF_MMA_BF16 ? (uint32_t)pack_pair<bf16x2, false>(x, y) : (uint32_t)pack_pair<f16x2, false>(x, y);
+            ((uint32_t*)a.out[k])[j] = convert_pair(x, y, a.mode[k], j);
         }
     }
 }
@@ -239,7 +251,7 @@ int launch_repack(const float* flat, const int32_t* src, int64_t n_elems, int mo
     } else {
         const int64_t pairs = n_elems / 2;
         hipLaunchKernelGGL(repack16_kernel, dim3((unsigned)((pairs + 255) / 256 < 4096 ? (pairs + 255) / 256 : 4096)), dim3(256), 0, s, flat, src, pairs,
-                           mode == NRF_MMA_BF16 ? 1 : 0, (uint32_t*)out);
+                           mode, (uint32_t*)out);
     }
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }

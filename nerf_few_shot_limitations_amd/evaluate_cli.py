@@ -1,5 +1,5 @@
 """python -m nerf_few_shot_limitations_amd.evaluate_cli --config experiments/baseline.yaml --data data/nerf_synthetic/lego \\
-        [--checkpoint results/.../best.pth] [--split test] [--out results/eval] [--mode f32|f16|bf16] [--max-views N]
+        [--checkpoint results/.../best.pth] [--split test] [--out results/eval] [--mode f16x3|f32|f16|bf16] [--max-views N]
 
 What `NeRFDINOTrainer.evaluate` does (src/training/train.py:294-342) for a use_dino=False config, on the fused renderer:
 load the YAML unchanged, the Blender split, the checkpoint (either key set), render every view (8 per launch), score
@@ -25,7 +25,8 @@ def main(argv=None):
     ap.add_argument("--checkpoint")
     ap.add_argument("--split", default="test")
     ap.add_argument("--out", default=None)
-    ap.add_argument("--mode", default="f32", choices=["f32", "f16", "bf16"])
+    ap.add_argument("--mode", default="f16x3", choices=["f16x3", "f32", "f16", "bf16"],
+                    help="f16x3 / f32: parity-grade (1e-4 of the reference); f16 / bf16: full MFMA rate")
     ap.add_argument("--max-views", type=int, default=None)
     ap.add_argument("--ert", type=float, default=0.0)
     ap.add_argument("--dino-map", default=None)

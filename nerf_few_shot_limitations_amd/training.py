@@ -102,8 +102,9 @@ def _grad_target(module):
 def _train_handle(module, dev):
     """nrf_model* with forward AND backward streams matching the current parameter values."""
     module.flat_params().ensure()
-    h = module.handle(dev)
-    mode = L.MMA_MODES[module.mma_mode]
+    train_mode = L.TRAIN_MODE[module.mma_mode]
+    h = module.handle(dev, train_mode)
+    mode = L.MMA_MODES[train_mode]
     if not module._train_ready:
         # first use: build the backward plan, then pack both directions from the flat vector
         with torch.cuda.device(dev):

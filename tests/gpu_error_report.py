@@ -27,20 +27,20 @@ H, W, S = int(e["H"]), int(e["W"]), int(e["S"])
 ro, rd = N.get_rays(H, W, float(e["focal"]), T(e["c2w"]))
 for variant in ("v1", "v2"):
     for scene in ("fog", "solid"):
-        for mode in ("f32", "f16", "bf16"):
+        for mode in ("f32", "f16x3", "f16", "bf16"):
             m, p = mk(variant, scene, mode)
             out = N.render_rays(m, ro, rd, 2.0, 6.0, S)
             print(f"e2e {variant} {scene} {mode}: rgb {md(out['rgb'], e[f'{variant}_{scene}_plain_rgb']):.2e} "
                   f"depth {md(out['depth'], e[f'{variant}_{scene}_plain_depth']):.2e} w {md(out['weights'], e[f'{variant}_{scene}_plain_w']):.2e}")
 for scene in ("fog", "solid"):
     gm = g(f"mlp_v1_{scene}")
-    for mode in ("f32", "f16", "bf16"):
+    for mode in ("f32", "f16x3", "f16", "bf16"):
         m, _ = mk("v1", scene, mode)
         with torch.no_grad():
             out = m(T(gm["x_enc"]))
         print(f"mlp_v1 {scene} {mode}: rgb {md(out[:, :3], gm['out'][:, :3]):.2e} sigma {md(out[:, 3], gm['out'][:, 3]):.2e} (|sigma|max {np.abs(gm['out'][:,3]).max():.1f})")
 gm = g("mlp_v2")
-for mode in ("f32", "f16", "bf16"):
+for mode in ("f32", "f16x3", "f16", "bf16"):
     m, _ = mk("v2", "fog", mode)
     with torch.no_grad():
         rgb, dens = m(T(gm["pos"]), T(gm["dirs"]), None)
@@ -51,7 +51,7 @@ for scene in ("fog", "solid"):
     p = O.make_weights("v1", 0, scene)
     roo, rdo = O.get_rays(Hc, Wc, O.focal_for(Wc), c2w)
     ref = O.render_rays(p, "v1", roo, rdo, 2.0, 6.0, Sc)
-    for mode in ("f32", "f16", "bf16"):
+    for mode in ("f32", "f16x3", "f16", "bf16"):
         m, _ = mk("v1", scene, mode)
         rgb, depth = N.render_camera(m, Hc, Wc, O.focal_for(Wc), c2w, 2.0, 6.0, Sc)
         print(f"100x100x32 v1 {scene} {mode}: rgb {md(rgb, ref['rgb'].numpy()):.2e} depth {md(depth, ref['depth'].numpy()):.2e} "

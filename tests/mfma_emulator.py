@@ -73,8 +73,9 @@ def dense(stream: Stream, bias_rows, in_regs, MT, quant):
     """One layer.  in_regs[KT][64][16] are the operand tiles as the kernel holds them (already
     quantised to the mode's operand type).  Returns raw accumulators out[MT][64][16]."""
     mode = stream.mode
-    KT = in_regs.shape[0]
-    SUB = 4 if mode == "f32" else 2
+    x3 = mode == "f16x3"                         # in_regs = [hi, lo] operand images (quantize())
+    KT = in_regs.shape[1] if x3 else in_regs.shape[0]
+    SUB = 4 if mode in ("f32", "f16x3") else 2
     stream.layer_start()
     out = np.zeros((MT, 64, 16), np.float32)
     lanes = np.arange(64)
@@ -93,6 +94,16 @@ def dense(stream: Stream, bias_rows, in_regs, MT, quant):
                         A[li, lh] = frag[lanes, e]
                         B[lh, li] = in_regs[t, lanes, 4 * s + e]
                         D += A @ B
+                elif x3:
+                    # split mode (mlp_core.hpp:ModeF16X3): fragment 2s' = W_hi -> X_hi and X_lo, fragment 2s'+1 = W_lo -> X_hi
+                    A = np.zeros((32, 16)); Bh = np.zeros((16, 32)); Bl = np.zeros((16, 32))
+                    for j in range(8):
+                        A[li, 8 * lh + j] = frag[lanes, j]
+                        Bh[8 * lh + j, li] = in_regs[0, t, lanes, 8 * (s >> 1) + j]
+                        Bl[8 * lh + j, li] = in_regs[1, t, lanes, 8 * (s >> 1) + j]
+                    D += A @ Bh
+                    if s % 2 == 0:
+                        D += A @ Bl
                 else:
                     A = np.zeros((32, 16)); B = np.zeros((16, 32))
                     for j in range(8):
@@ -110,4 +121,9 @@ def quantize(x, mode):
         return bf16_round(x)
     if mode == "f16":
         return np.asarray(x, np.float32).astype(np.float16).astype(np.float32)
+    if mode == "f16x3":
+        x = np.clip(np.asarray(x, np.float32), -65504.0, 65504.0)
+        hi = x.astype(np.float16).astype(np.float32)
+        lo = (x - hi).astype(np.float16).astype(np.float32)
+        return np.stack([hi, lo])
     return np.asarray(x, np.float32)

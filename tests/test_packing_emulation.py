@@ -79,7 +79,7 @@ def _encode_tiles(x, Lf):
     return E.tiles_from_matrix(X)
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("f16", 3e-3), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("f16", 3e-3), ("bf16", 3e-2)])
 def test_v1_stream_replay_matches_oracle(L, mode, tol):
     p = O.make_weights("v1", 0)
     raw, bias = _pack(L, "v1", p, mode)
@@ -104,7 +104,7 @@ def test_v1_stream_replay_matches_oracle(L, mode, tol):
     assert np.array_equal(got, got_hi)
 
 
-@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("mode,tol", [("f32", 2e-5), ("f16x3", 2e-5), ("bf16", 3e-2)])
 def test_v2_stream_replay_matches_oracle(L, mode, tol):
     p = O.make_weights("v2", 1)
     raw, bias = _pack(L, "v2", p, mode)
@@ -120,7 +120,7 @@ def test_v2_stream_replay_matches_oracle(L, mode, tol):
         boff += 256
     dens = E.dense(st, bias[boff:boff + 32], act, 1, mode); boff += 32
     feat = E.quantize(E.dense(st, bias[boff:boff + 256], act, 8, mode), mode); boff += 256
-    in9 = np.concatenate([feat, dirt], 0)
+    in9 = np.concatenate([feat, dirt], -3)                                  # tile axis (the split mode's images carry a leading hi/lo axis)
     c0 = E.quantize(np.maximum(E.dense(st, bias[boff:boff + 128], in9, 4, mode), 0), mode); boff += 128
     c1 = E.quantize(np.maximum(E.dense(st, bias[boff:boff + 64], c0, 2, mode), 0), mode); boff += 64
     rgb = E.dense(st, bias[boff:boff + 32], c1, 1, mode); boff += 32

@@ -1,27 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- M ray-samples/s of the fused sample+encode+MLP+composite renderer.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
 
 Workload (BASELINE.json metric): synthetic 800x800 camera frames, 64 samples per ray, the 8x256
 NeRF MLP (nerf_model.NeRFMLP, 951 808 FLOP per ray-sample), deterministic random-init weights
-("solid" scene; early ray termination OFF, so every one of the R*S samples is evaluated), bf16 MFMA.  One step renders
-n_gpus views of the sensor: every view's rays are cut into 16-row pixel tiles dealt round-robin over
-the ranks (per-GPU work is one frame's worth of rays whatever N is: weak scaling); each rank renders
-its tiles of ALL views with ONE kernel launch and the finished tiles are exchanged with ONE RCCL
-all_gather per step so that every rank holds all frames.  Inputs are generated in-kernel (camera mode): nothing is read
-from the host in the timed region.
+("solid" scene; early ray termination OFF, so every one of the R*S samples is evaluated), bf16 MFMA.
+
+--scaling weak (default): one step renders n_gpus views of the sensor: every view's rays are cut into 16-row pixel tiles
+dealt round-robin over the ranks, so per-GPU work is one frame's worth of rays whatever N is; each rank renders its
+tiles of ALL views with ONE kernel launch straight into the gather buffer and the tiles are exchanged with ONE RCCL
+all_gather per step so that every rank holds all frames.  --scaling strong: ONE view per step cut over the ranks
+(BASELINE.json config 5's shape with --samples 128).  Whichever is the headline, the other one is measured too (a few
+steps after the timed region) and reported as `strong_scaling` / `weak_scaling`; the all_gather is timed separately
+(`gather_ms`).  Inputs are generated in-kernel (camera mode): nothing is read from the host in the timed region.
 
 The JSON line also carries
-  roofline     -- algorithmic FLOPs of the render kernel / its mean launch duration (HIP events on
-                  the launch stream) against the dense bf16 MFMA peak (2.5 PFLOP/s);
-  cpu_baseline -- the CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch CPU
-                  path) timed on a band of rows of the same frame on this host's cores;
-  parity       -- max abs error / PSNR of the benchmarked mode (and of the fp32 parity mode) vs that oracle band, and the
-                  PSNR delta of both against a common ground truth (the band marched with 2x the samples).
+  roofline     -- algorithmic FLOPs of the render kernel / its mean launch duration (HIP events on the launch stream)
+                  against the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline -- the CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch CPU path) timed on a band of
+                  rows of the same frame on this host's cores;
+  parity       -- max abs error / PSNR of every arithmetic mode vs that oracle band, and the PSNR delta against a common
+                  ground truth (the band marched with 2x the samples);
+  parity_mode  -- the parity-grade fast mode (f16x3: split-f16, 3 MFMAs per product): ms per frame, TFLOP/s credited 1x,
+                  fraction of the 2.5 PFLOP/s peak -- the mode that meets the 1e-4 / 0.01 dB bars -- beside f16 and f32;
+  ert          -- early ray termination on the "smooth" scene: ms, speed-up, max |d rgb| vs the full march (must be <= eps).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -40,15 +47,16 @@ def training_line(N, args, dev):
     reference's own batch (baseline.yaml:32-34: 2048 rays x 32 samples), random-init weights, through training.FusedStep."""
     from nerf_few_shot_limitations_amd.training import FusedStep
     R, S = 2048, 32
+    mode = args.mode if args.mode != "f16x3" else "f32"
     torch.manual_seed(0)
     if args.net == "v3":
-        m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=args.mode).to(dev).train()
+        m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=mode).to(dev).train()
         pts = torch.rand(R * S, 3, device=dev) * 4 - 2
     elif args.net == "v2":
-        m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=args.mode).to(dev).train()
+        m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=mode).to(dev).train()
         pts = torch.rand(R * S, 3, device=dev) * 4 - 2
     else:
-        m = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=args.mode).to(dev).train()
+        m = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=mode).to(dev).train()
         pts = torch.rand(R * S, 63, device=dev) * 2 - 1
     dirs = torch.rand(R * S, 3, device=dev) * 2 - 1
     z = torch.sort(torch.rand(R, S, device=dev) * 4 + 2, dim=-1).values.contiguous()
@@ -70,8 +78,8 @@ def training_line(N, args, dev):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k
     return {"metric": "M ray-samples/s per optimisation step (forward + backward + Adam)", "value": round(R * S / dt / 1e6, 2),
-            "ms_per_step": round(dt * 1e3, 4), "rays": R, "samples_per_ray": S, "net": args.net, "dtype": args.mode,
-            "loss_first": round(first, 6), "loss_last": round(loss.item(), 6), "bound": "hbm (saved activations, profiles/r01_train_pmc_summary.json)"}
+            "ms_per_step": round(dt * 1e3, 4), "rays": R, "samples_per_ray": S, "net": args.net, "dtype": mode,
+            "loss_first": round(first, 6), "loss_last": round(loss.item(), 6)}
 
 
 def main():
@@ -86,11 +94,16 @@ def main():
     ap.add_argument("--net", default="v1", choices=["v1", "v2", "v3"])
     ap.add_argument("--scene", default="solid", choices=["fog", "solid", "smooth"])
     ap.add_argument("--ert", type=float, default=0.0)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: n_gpus views per step (one frame's worth of rays per GPU); strong: ONE view per step cut over the ranks")
+    ap.add_argument("--other-steps", type=int, default=10, help="steps of the other scaling mode measured after the timed region (0 = skip)")
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per pixel tile; 0 = largest <= 16 that deals the tiles evenly")
     ap.add_argument("--no-train", action="store_true", help="skip the optimisation-step timing appended as 'training' (N=1 only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the parity_mode / ert legs (N=1 only)")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
     args = ap.parse_args()
 
+    # one rank per GPU, decided from the launcher's environment BEFORE anything touches a device
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -112,60 +125,50 @@ def main():
             dist.init_process_group(backend=backend)
 
     import nerf_few_shot_limitations_amd as N
+    from nerf_few_shot_limitations_amd import tiles
     from oracle import nerf_oracle as O               # cpu_baseline / parity legs only
 
     H, W, S = args.height, args.width, args.samples
     c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
     focal = O.focal_for(W)
     seed = {"v1": 0, "v2": 1, "v3": 2}[args.net]
-    p = O.make_weights(args.net, seed, args.scene)
+
+    def make_model(scene, mode):
+        p = O.make_weights(args.net, seed, scene)
+        if args.net == "v1":
+            m = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=mode)
+            m.load_state_dict(p)
+        elif args.net == "v2":
+            m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=mode)
+            m.load_state_dict(p, strict=False)
+        else:
+            m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=mode)
+            m.load_state_dict(p, strict=False)
+        return m.to(dev).eval(), p
+
+    model, p = make_model(args.scene, args.mode)
     dino = None
-    if args.net == "v1":
-        model = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=args.mode)
-        model.load_state_dict(p)
-    elif args.net == "v2":
-        model = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=args.mode)
-        model.load_state_dict(p, strict=False)
-    else:
-        model = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=args.mode)
-        model.load_state_dict(p, strict=False)
+    if args.net == "v3":
         fm = torch.from_numpy(O.uniform01(7, 28 * 28 * 64).reshape(1, 28, 28, 64) * 2 - 1)
         dino = dict(features=fm, pose=c2w, focal=focal, H=H, W=W)
-    model = model.to(dev).eval()
     flops_per_sample = model.flops_per_sample()
 
-    # one step = `world` views of the same sensor (the camera orbits the scene), tile-sharded over the ranks
-    import math
-    from nerf_few_shot_limitations_amd import tiles
-    n_frames = world
-    poses = []
-    for v in range(n_frames):
-        th = 2 * math.pi * v / 8
-        rz = torch.tensor([[math.cos(th), -math.sin(th), 0, 0], [math.sin(th), math.cos(th), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
-        poses.append(rz @ c2w)
-    poses = torch.stack(poses)
+    def orbit(n):
+        poses = []
+        for v in range(n):
+            th = 2 * math.pi * v / 8
+            rz = torch.tensor([[math.cos(th), -math.sin(th), 0, 0], [math.sin(th), math.cos(th), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=torch.float32)
+            poses.append(rz @ c2w)
+        return torch.stack(poses)
+
     tile_rows = args.tile_rows
     if tile_rows <= 0:
         even = [r for r in range(16, 0, -1) if H % r == 0 and (H // r) % world == 0]
         tile_rows = even[0] if even else 16
     tile_rays = tile_rows * W
-    job = tiles.TileJob(model, H, W, focal, poses, 2.0, 6.0, S, rank, world, tile_rays, ert_eps=args.ert, device=dev, dino=dino)
-    ev = []
 
-    def step(timed):
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        job.launch()                                   # ONE render kernel launch: this rank's tiles of all views
-        if timed:
-            e1.record()
-            ev.append((e0, e1))
-        local = job.pack()
-        if world == 1:
-            return local
-        if backend != "nccl":
-            return tiles.gather_frames(local.cpu(), H * W, tile_rays)
-        return tiles.gather_frames(local, H * W, tile_rays)                            # ONE all_gather (RCCL)
+    def make_job(n_views):
+        return tiles.TileJob(model, H, W, focal, orbit(n_views), 2.0, 6.0, S, rank, world, tile_rays, ert_eps=args.ert, device=dev, dino=dino)
 
     def sync():
         torch.cuda.synchronize()
@@ -173,52 +176,95 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    sync()
-    print(f"[bench] rank {rank}: warmup done", file=sys.stderr, flush=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def run(job, steps, warmup):
+        """`warmup` untimed + `steps` timed steps of one job: (wall seconds [max over ranks], mean kernel ms, mean gather ms)."""
+        kev, gev = [], []
 
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(len(ev), 1)
+        def step(timed):
+            if timed:
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+            job.launch()                                   # ONE render kernel launch: this rank's tiles of all views, written
+            if timed:                                      # straight into the gather buffer
+                e1.record()
+            if world > 1:
+                if backend != "nccl":
+                    tiles.gather_frames(job.buf.cpu(), H * W, tile_rays)
+                else:
+                    tiles.gather_frames(job.buf, H * W, tile_rays)         # ONE all_gather (RCCL) + the view into frame order
+            if timed:
+                e2.record()
+                kev.append((e0, e1)); gev.append((e1, e2))
+
+        for _ in range(warmup):
+            step(False)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        kms = sum(a.elapsed_time(b) for a, b in kev) / max(len(kev), 1)
+        gms = sum(a.elapsed_time(b) for a, b in gev) / max(len(gev), 1) if world > 1 else None
+        return dt, kms, gms
+
+    views_main = world if args.scaling == "weak" else 1
+    job = make_job(views_main)
+    dt, kernel_ms, gather_ms = run(job, args.steps, args.warmup)
+    print(f"[bench] rank {rank}: timed region done", file=sys.stderr, flush=True)
+
     samples_per_launch = job.rays_per_launch * S
-    samples_per_step = n_frames * H * W * S                     # all ranks together
+    samples_per_step = views_main * H * W * S                     # all ranks together
     value = samples_per_step * args.steps / dt / 1e6
     achieved = samples_per_launch * flops_per_sample / (kernel_ms * 1e-3) / 1e12
 
-    # HBM bytes per launch come from PMC counters, which bench.py cannot collect itself: they are read from the
-    # committed rocprofv3 summary of this very workload (profiles/r01_pmc_summary.json), else reported as null
-    traffic = None
-    try:
-        if (args.net, args.mode, H, W, S, world) == ("v1", "bf16", 800, 800, 64, 1):
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-                traffic = json.load(f)["derived"]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        traffic = None
+    # HBM bytes per launch come from PMC counters, which bench.py cannot collect itself: a STATIC figure read from the
+    # committed rocprofv3 summary of this very workload (profiles/), else null
+    traffic, traffic_src = None, None
+    if (args.net, args.mode, H, W, S, world, args.scaling) == ("v1", "bf16", 800, 800, 64, 1, "weak"):
+        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    traffic = json.load(f)["derived"]["hbm_bytes_per_launch"]
+                traffic_src = f"static (profiled offline): profiles/{name} (FETCH_SIZE*2 + WRITE_SIZE, bytes per launch)"
+                break
+            except (OSError, KeyError, ValueError):
+                continue
 
     out = {
         "metric": "M ray-samples/sec (sample+MLP+composite) at 800^2x64",
         "value": round(value, 2), "unit": "M ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.mode, "data": "synthetic",
         "config": {"workload": f"{H}x{W} camera frame x {S} samples/ray, NeRFMLP {args.net} 8x256, scene {args.scene}, "
-                               f"{n_frames} view(s)/step, {tile_rows}-row pixel tiles dealt round-robin over {world} GPU(s), one launch + one all_gather per step",
+                               f"{views_main} view(s)/step, {tile_rows}-row pixel tiles dealt round-robin over {world} GPU(s), one launch + one all_gather per step",
                    "rays_per_gpu_per_step": job.rays_per_launch, "samples_per_ray": S, "ert_eps": args.ert,
                    "flops_per_sample": flops_per_sample, "parallelism": f"pixel-tile x{world}"},
+        "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.mode], "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": traffic,
-                     "traffic_source": "profiles/r01_pmc_summary.json (FETCH_SIZE*2 + WRITE_SIZE, bytes per launch)" if traffic else None,
-                     "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": len(ev)},
+                     "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": args.steps},
     }
 
-    if rank == 0 and world == 1 and args.cpu_rows > 0:
+    # the other scaling mode, a few steps (every rank takes part)
+    if args.other_steps > 0 and world > 1:
+        other = "strong" if args.scaling == "weak" else "weak"
+        views_o = 1 if other == "strong" else world
+        job_o = make_job(views_o)
+        dto, kmo, gmo = run(job_o, args.other_steps, 2)
+        out[f"{other}_scaling"] = {
+            "workload": f"{views_o} view(s) of {H}x{W}x{S} per step cut over {world} GPU(s)", "steps": args.other_steps,
+            "value": round(views_o * H * W * S * args.other_steps / dto / 1e6, 2), "unit": "M ray-samples/s",
+            "ms_per_step": round(dto / args.other_steps * 1e3, 4), "kernel_ms": round(kmo, 4), "gather_ms": None if gmo is None else round(gmo, 4),
+            "rays_per_gpu_per_step": job_o.rays_per_launch}
+        del job_o
+
+    single = rank == 0 and world == 1
+    if single and args.cpu_rows > 0:
         # CPU oracle on a band of rows of the same frame (port of the reference's torch-CPU path)
         # the box's CPU share, not the host's core count (a cgroup-limited box reports far more cores than it may use)
         threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("NERF_BENCH_CPU_THREADS", "16")))
@@ -240,27 +286,59 @@ def main():
         out["cpu_baseline"] = {"value": round(rows * W * S / best / 1e6, 4), "unit": "M ray-samples/s", "cores": threads,
                                "kind": "port", "sample": f"{rows} rows ({rows * W} rays x {S} samples) of the same {H}x{W} frame, "
                                                           f"torch fp32 CPU, chunk 2048 rays, best of 3"}
-        rgb_b, depth_b = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, ert_eps=args.ert, device=dev, dino=dino)
-        rgb32, depth32 = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f32", device=dev, dino=dino)
-        rgb16, _ = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode="f16", device=dev, dino=dino)
-        torch.cuda.synchronize()
         # PSNR delta against a common ground truth (the lego images are not available offline: SURVEY.md section 8d):
-        # GT = the same rows marched with twice the samples by the CPU oracle; both renderers at S samples vs that GT
+        # GT = the same rows marched with twice the samples by the CPU oracle; every mode at S samples vs that GT
         gt = O.render_rays(p, args.net, ro, rd, 2.0, 6.0, 2 * S, chunk=2048, dino=dino)["rgb"]
         ps_ref = O.psnr(ref["rgb"], gt)
-        out["parity"] = {
-            "band_rows": rows,
-            "psnr_oracle_vs_gt_db": round(ps_ref, 3),
-            f"psnr_delta_{args.mode}_db": round(abs(O.psnr(rgb_b.cpu(), gt) - ps_ref), 4),
-            "psnr_delta_f32_db": round(abs(O.psnr(rgb32.cpu(), gt) - ps_ref), 6),
-            "psnr_delta_f16_db": round(abs(O.psnr(rgb16.cpu(), gt) - ps_ref), 4),
-            f"{args.mode}_max_abs_rgb": float((rgb_b.cpu() - ref["rgb"]).abs().max()),
-            f"{args.mode}_max_abs_depth": float((depth_b.cpu() - ref["depth"]).abs().max()),
-            f"{args.mode}_psnr_vs_oracle_db": round(O.psnr(rgb_b.cpu(), ref["rgb"]), 2),
-            "f32_max_abs_rgb": float((rgb32.cpu() - ref["rgb"]).abs().max()),
-            "f32_max_abs_depth": float((depth32.cpu() - ref["depth"]).abs().max()),
-        }
-    if rank == 0 and world == 1 and not args.no_train:
+        par = {"band_rows": rows, "psnr_oracle_vs_gt_db": round(ps_ref, 3)}
+        for mode in ("bf16", "f16", "f16x3", "f32"):
+            rgb_m, depth_m = N.render_camera(model, H, W, focal, c2w, 2.0, 6.0, S, ray_begin=r0, ray_end=r1, mma_mode=mode, device=dev, dino=dino)
+            torch.cuda.synchronize()
+            par[mode] = {"max_abs_rgb": float((rgb_m.cpu() - ref["rgb"]).abs().max()), "max_abs_depth": float((depth_m.cpu() - ref["depth"]).abs().max()),
+                         "psnr_vs_oracle_db": round(O.psnr(rgb_m.cpu(), ref["rgb"]), 2),
+                         "psnr_delta_db": round(abs(O.psnr(rgb_m.cpu(), gt) - ps_ref), 6),
+                         "meets_1e-4": bool(float((rgb_m.cpu() - ref["rgb"]).abs().max()) <= 1e-4 and float((depth_m.cpu() - ref["depth"]).abs().max()) <= 1e-4),
+                         "meets_0.01dB": bool(abs(O.psnr(rgb_m.cpu(), gt) - ps_ref) <= 0.01)}
+        out["parity"] = par
+
+    if single and not args.no_extras:
+        def time_frames(mdl, mode, reps, **kw):
+            """mean HIP-event ms of `reps` whole-frame launches (one warm-up first)"""
+            N.render_camera(mdl, H, W, focal, c2w, 2.0, 6.0, S, mma_mode=mode, device=dev, dino=dino, **kw)
+            torch.cuda.synchronize()
+            ev = []
+            for _ in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                res = N.render_camera(mdl, H, W, focal, c2w, 2.0, 6.0, S, mma_mode=mode, device=dev, dino=dino, **kw)
+                e1.record()
+                ev.append((e0, e1))
+            torch.cuda.synchronize()
+            return sum(a.elapsed_time(b) for a, b in ev) / reps, res
+
+        # the parity-grade fast mode next to the other modes, same frame, credited 1x the algorithmic FLOPs
+        pm = {}
+        for mode, reps in (("f16x3", 5), ("f16", 10), ("f32", 3)):
+            ms, _ = time_frames(model, mode, reps)
+            tf = H * W * S * flops_per_sample / (ms * 1e-3) / 1e12
+            pm[mode] = {"ms_per_frame": round(ms, 3), "M_ray_samples_per_s": round(H * W * S / ms / 1e3, 1), "TFLOP_per_s_credited": round(tf, 1),
+                        "frac_of_2.5PF": round(tf / 2500.0, 4)}
+        pm["mode"] = "f16x3"
+        pm["note"] = ("f16x3 = split f16 (hi+lo operands, 3 MFMAs per product at the 32x32x16 rate): meets the 1e-4 abs and 0.01 dB bars (see parity); "
+                      "f16 meets the 0.01 dB bar only; bf16 (the headline) neither; f32 = exact fp32 MFMA at 1/16 rate")
+        out["parity_mode"] = pm
+        # early ray termination where it can act: the coherent opaque "smooth" scene
+        eps = 1e-2
+        ms_mod, _ = make_model("smooth", args.mode)
+        ms_off, full = time_frames(ms_mod, args.mode, 5)
+        ms_on, ert = time_frames(ms_mod, args.mode, 5, ert_eps=eps)
+        ms_solid_off, _ = time_frames(model, args.mode, 5)
+        ms_solid_on, _ = time_frames(model, args.mode, 5, ert_eps=1e-30)         # nothing terminates: the cost of the ERT machinery alone
+        out["ert"] = {"scene": "smooth", "eps": eps, "ms_off": round(ms_off, 3), "ms_on": round(ms_on, 3), "speedup": round(ms_off / ms_on, 3),
+                      "max_abs_rgb_vs_full_march": float((ert[0] - full[0]).abs().max()), "max_abs_depth_vs_full_march": float((ert[1] - full[1]).abs().max()),
+                      "no_termination_overhead": {"scene": args.scene, "ms_plain": round(ms_solid_off, 3), "ms_ert_kernel": round(ms_solid_on, 3),
+                                                  "ratio": round(ms_solid_on / ms_solid_off, 4)}}
+    if single and not args.no_train:
         out["training"] = training_line(N, args, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 2
+#define NRF_ABI_VERSION 3
 
 /* error codes */
 #define NRF_OK            0
@@ -102,6 +102,8 @@ typedef struct nrf_render_opts {
     int32_t  white_bkgd;     /* nerf_mlp.py:209-212                                                   */
     int32_t  mma_mode;       /* NRF_MMA_*                                                             */
     const nrf_dino* dino;    /* V3 only (host struct, copied at launch)                               */
+    int32_t  out_rgbd;       /* 1: `rgb` points at (R,4) rows [r,g,b,depth] written with one 16-byte store per ray (16-byte aligned)
+                                and `depth` is ignored (may be NULL) -- the layout of the multi-GPU gather buffer; 0: (R,3) + (R) */
 } nrf_render_opts;
 
 /* ---- model handle -------------------------------------------------------- */

@@ -46,7 +46,7 @@ class nrf_dino(C.Structure):
 class nrf_render_opts(C.Structure):
     _fields_ = [("near", C.c_float), ("far", C.c_float), ("n_samples", C.c_int32), ("lindisp", C.c_int32),
                 ("perturb", C.c_int32), ("t_rand", C.c_void_p), ("z_ladder", C.c_void_p), ("z_in", C.c_void_p), ("rng_seed", C.c_uint64), ("ert_eps", C.c_float),
-                ("white_bkgd", C.c_int32), ("mma_mode", C.c_int32), ("dino", C.POINTER(nrf_dino))]
+                ("white_bkgd", C.c_int32), ("mma_mode", C.c_int32), ("dino", C.POINTER(nrf_dino)), ("out_rgbd", C.c_int32)]
 
 
 # name -> (restype, argtypes); tests/test_packing_emulation.py checks this table against include/nerfhip.h
@@ -114,7 +114,7 @@ def lib() -> C.CDLL:
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(handle, name)          # AttributeError if the symbol is not exported
                 fn.restype, fn.argtypes = res, args
-            if handle.nrf_abi_version() != 2:
+            if handle.nrf_abi_version() != 3:
                 raise RuntimeError("libnerfhip.so ABI version mismatch")
             for which, st in enumerate((nrf_arch, nrf_linear, nrf_dino, nrf_render_opts)):
                 if handle.nrf_abi_sizeof(which) != C.sizeof(st):

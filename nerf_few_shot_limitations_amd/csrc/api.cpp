@@ -221,6 +221,7 @@ void fill_common(nrf::RenderArgs& a, const nrf_render_opts* o, float* rgb, float
     a.near = o->near; a.far = o->far; a.n_samples = o->n_samples; a.lindisp = o->lindisp; a.perturb = o->perturb;
     a.t_rand = o->perturb ? o->t_rand : nullptr; a.z_ladder = o->z_ladder; a.z_in = o->z_in; a.seed = o->rng_seed;
     a.ert_eps = o->ert_eps; a.white_bkgd = o->white_bkgd;
+    a.interleaved = o->out_rgbd ? 1 : 0;
     a.rgb = rgb; a.depth = depth; a.weights = weights; a.z_vals = z_vals;
 }
 
@@ -308,9 +309,9 @@ int nrf_render_rays(const nrf_model* m, const float* rays_o, const float* rays_d
     if (!m) return fail(NRF_EINVAL, "model is NULL");
     if (n_rays < 0) return fail(NRF_EINVAL, "n_rays < 0");
     if (n_rays == 0) return NRF_OK;
-    if (!rays_o || !rays_d || !rgb || !depth) return fail(NRF_EINVAL, "nrf_render_rays: null ray or output pointer");
     const int rc = check_opts(opts);
     if (rc != NRF_OK) return rc;
+    if (!rays_o || !rays_d || !rgb || (!depth && !opts->out_rgbd)) return fail(NRF_EINVAL, "nrf_render_rays: null ray or output pointer");
     if ((int64_t)opts->n_samples * n_rays > (int64_t)1 << 40) return fail(NRF_EINVAL, "ray-sample count too large");
     nrf::RenderArgs a{};
     a.rays_o = rays_o; a.rays_d = rays_d; a.camera_mode = 0; a.ray_begin = 0; a.n_rays = n_rays;
@@ -330,9 +331,9 @@ int nrf_render_camera(const nrf_model* m, int H, int W, float focal, const float
     if (H < 1 || W < 1 || !(focal > 0.0f) || !c2w) return fail(NRF_EINVAL, "bad camera");
     if (ray_begin < 0 || ray_end < ray_begin || ray_end > (int64_t)H * W) return fail(NRF_EINVAL, "ray range outside the image");
     if (ray_end == ray_begin) return NRF_OK;
-    if (!rgb || !depth) return fail(NRF_EINVAL, "nrf_render_camera: null output pointer");
     const int rc = check_opts(opts);
     if (rc != NRF_OK) return rc;
+    if (!rgb || (!depth && !opts->out_rgbd)) return fail(NRF_EINVAL, "nrf_render_camera: null output pointer");
     nrf::RenderArgs a{};
     a.camera_mode = 1; a.n_cams = 1; a.cams[0] = make_camera(H, W, focal, c2w); a.ray_begin = ray_begin; a.n_rays = ray_end - ray_begin;
     a.rays_per_cam = a.n_rays; a.tile_rays = a.n_rays; a.tile_stride = 0;
@@ -354,9 +355,9 @@ int nrf_render_cameras_tiles(const nrf_model* m, int H, int W, float focal, cons
     if (tile_rays < 1 || first_tile < 0 || tile_step < 1 || n_tiles < 0) return fail(NRF_EINVAL, "bad tile description");
     if (n_tiles == 0) return NRF_OK;
     if (first_tile * tile_rays >= (int64_t)H * W) return fail(NRF_EINVAL, "first tile lies outside the image");
-    if (!rgb || !depth) return fail(NRF_EINVAL, "nrf_render_cameras_tiles: null output pointer");
     const int rc = check_opts(opts);
     if (rc != NRF_OK) return rc;
+    if (!rgb || (!depth && !opts->out_rgbd)) return fail(NRF_EINVAL, "nrf_render_cameras_tiles: null output pointer");
     if (opts->t_rand || opts->z_in) return fail(NRF_EINVAL, "tile rendering takes no per-ray inputs (t_rand and z_in must be NULL)");
     nrf::RenderArgs a{};
     a.camera_mode = 1; a.n_cams = n_cams;

@@ -105,13 +105,23 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, a.z_ladder);
     const int own = (NT == 2) ? h : 0;
     const bool owner = h < NT;
+    // Samples per ray and MLP pass (host: pick_spw_log2).  The wave's 32 sample columns are RPW = 32/SPW rays x SPW consecutive
+    // samples: column c = ray (c mod RPW), sample (pass*SPW + c div RPW).  A ray is still composited front to back by ONE lane
+    // (column c < RPW), which fetches the other columns' network outputs with ds_bpermute -- the per-ray sequence of operations,
+    // hence every bit of the result, does not depend on SPW.  What SPW buys: frames whose ray count does not fill whole rounds
+    // of 256-ray tiles over the CUs (400x400; an 80 000-ray shard) are cut into 2x / 4x as many, shorter, work items.
+    const int spw_log2 = (NT == 1 && !ERT) ? a.spw_log2 : 0;
+    const int SPW = 1 << spw_log2, RPW = 32 >> spw_log2;
+    const int cr = c & (RPW - 1), cj = c >> (5 - spw_log2);
+    const int64_t tile_rays = (int64_t)WAVES * NT * RPW;
+    const int n_pass = (S + SPW - 1) >> spw_log2;
 
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
         int64_t rid[NT];
         float o[NT][3], d[NT][3];
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int64_t r = tile * TILE + wave * (32 * NT) + 32 * n + c;
+            const int64_t r = tile * tile_rays + wave * (RPW * NT) + RPW * n + cr;
             rid[n] = r < a.n_rays ? r : a.n_rays - 1;
             if (a.camera_mode) {
                 int ci;
@@ -123,8 +133,8 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             }
         }
         const int64_t own_rid = (own == 0) ? rid[0] : rid[NT - 1];
-        const int64_t own_raw = tile * TILE + wave * (32 * NT) + 32 * own + c;
-        const bool own_valid = owner && own_raw < a.n_rays;
+        const int64_t own_raw = tile * tile_rays + wave * (RPW * NT) + RPW * own + cr;
+        const bool own_valid = owner && cj == 0 && own_raw < a.n_rays;
         float own_d[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) own_d[k] = (own == 0) ? d[0][k] : d[NT - 1][k];
@@ -157,31 +167,34 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
         Composite comp;
         comp.reset();
         pipe.skip = 0;
-        float zc[NT], zn[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) zc[n] = z_ray(rid[n], 0);
+        float zo = z_ray(own_rid, 0);            // depth of the own ray's next sample to composite
+        int done = 0;                            // samples composited so far
 
-        int s = 0;
-        for (; s < S; ++s) {
-            const bool last = (s + 1 == S);
+        for (int p = 0; p < n_pass; ++p) {
+            // depth of this column's sample (columns past the last sample repeat it; their outputs are not used)
+            float zc[NT];
+            {
+                const int sc = p * SPW + cj;
+                const int se = sc < S ? sc : S - 1;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) zn[n] = last ? 0.0f : z_ray(rid[n], s + 1);
+                for (int n = 0; n < NT; ++n) zc[n] = (SPW == 1 && n == own) ? zo : z_ray(rid[n], se);
+            }
 
             // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
             auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
                 if constexpr (ERT) if (pipe.skip) return;     // terminated wave: its layers are skipped too, nothing reads x
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
-                    float p[3];
+                    float pt[3];
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) p[k] = point_on_ray(o[n][k], d[n][k], zc[n]);
+                    for (int k = 0; k < 3; ++k) pt[k] = point_on_ray(o[n][k], d[n][k], zc[n]);
                     Act e1[KT0];
-                    encode3<Mode, LP>(p, h, e1, w0[n]);
+                    encode3<Mode, LP>(pt, h, e1, w0[n]);
 #pragma unroll
                     for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                     if constexpr (Net::kDino) {
                         constexpr int DT = Net::KT0 - KT0;
-                        const DinoTaps tp = dino_taps(a.dino, p);
+                        const DinoTaps tp = dino_taps(a.dino, pt);
                         Act dt[DT];
                         dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
 #pragma unroll
@@ -193,43 +206,58 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             float out4[NT][4];
             Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
 
-            float v[4];
+            float v0[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (own == 0) ? out4[0][k] : out4[NT - 1][k];
-            const float z_own = (own == 0) ? zc[0] : zc[NT - 1];
-            const float zn_own = (own == 0) ? zn[0] : zn[NT - 1];
-            const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn_own, z_own), norm);
-            float w = 0.0f;
-            if (!ERT || !pipe.skip)      // a terminated wave's MLP outputs are stale registers: they must not reach the accumulators
-                w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
-                                                      sigmoid_sel<Mode::FAST_EXP>(v[2]), z_own, dist);
-            if (own_valid) {
-                if (a.weights) a.weights[own_rid * S + s] = w;
-                if (a.z_vals) a.z_vals[own_rid * S + s] = z_own;
+            for (int k = 0; k < 4; ++k) v0[k] = (own == 0) ? out4[0][k] : out4[NT - 1][k];
+            for (int j = 0; j < SPW; ++j) {
+                const int s = p * SPW + j;
+                if (s >= S) break;
+                const bool last = (s + 1 == S);
+                float v[4];
+                if (j == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = v0[k];
+                } else {
+                    // the outputs of sample s of this lane's ray sit in column c + j*RPW of the same lane half
+                    const int src = (lane + j * RPW) << 2;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v0[k])));
+                }
+                const float zn = last ? 0.0f : z_ray(own_rid, s + 1);
+                const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zo), norm);
+                float w = 0.0f;
+                if (!ERT || !pipe.skip)      // a terminated wave's MLP outputs are stale registers: they must not reach the accumulators
+                    w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
+                                                          sigmoid_sel<Mode::FAST_EXP>(v[2]), zo, dist);
+                if (own_valid) {
+                    if (a.weights) a.weights[own_rid * S + s] = w;
+                    if (a.z_vals) a.z_vals[own_rid * S + s] = zo;
+                }
+                zo = zn;
+                done = s + 1;
             }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) zc[n] = zn[n];
 
-            if (ERT && a.ert_eps > 0.0f && !last) {
-                // early termination: a wave whose rays are all opaque stops computing (pipe.skip), the workgroup
-                // leaves the sample loop once all of its waves have
+            if (ERT && a.ert_eps > 0.0f && done < S) {
+                // early termination (SPW = 1 here: p is the sample index): a wave whose rays are all opaque stops computing
+                // (pipe.skip), the workgroup leaves the sample loop once all of its waves have
                 const int wave_dead = __all((!own_valid) || (comp.T < a.ert_eps));
                 pipe.skip = (uint32_t)__builtin_amdgcn_readfirstlane(wave_dead ? 1 : 0);   // provably wave-uniform: scalar branch
-                if ((s & 3) == 3) {       // the workgroup-wide vote (LDS flag + barrier) only every fourth step
-                    if (lane == 0) flags[((s >> 2) & 1) * WAVES + wave] = wave_dead;
+                if ((p & 3) == 3) {       // the workgroup-wide vote (LDS flag + barrier) only every fourth step
+                    if (lane == 0) flags[((p >> 2) & 1) * WAVES + wave] = wave_dead;
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
-                    const NRF_LDS int* fl = flags + ((s >> 2) & 1) * WAVES;
+                    const NRF_LDS int* fl = flags + ((p >> 2) & 1) * WAVES;
                     int all_dead = 1;
 #pragma unroll
                     for (int wv = 0; wv < WAVES; ++wv) all_dead &= fl[wv];
-                    if (all_dead) { ++s; break; }
+                    if (all_dead) break;
                 }
             }
         }
         if (own_valid) {
             // samples skipped by early termination carry weight < ert_eps: report 0 and their depths
-            for (int s2 = s; s2 < S; ++s2) {
+            for (int s2 = done; s2 < S; ++s2) {
                 if (a.weights) a.weights[own_rid * S + s2] = 0.0f;
                 if (a.z_vals) a.z_vals[own_rid * S + s2] = z_ray(own_rid, s2);
             }
@@ -238,10 +266,14 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                 const float bg = __fsub_rn(1.0f, comp.acc);
                 r = __fadd_rn(r, bg); g = __fadd_rn(g, bg); b = __fadd_rn(b, bg);
             }
-            a.rgb[own_rid * 3 + 0] = r;
-            a.rgb[own_rid * 3 + 1] = g;
-            a.rgb[own_rid * 3 + 2] = b;
-            a.depth[own_rid] = comp.depth;
+            if (a.interleaved) {
+                *(float4*)(a.rgb + own_rid * 4) = make_float4(r, g, b, comp.depth);     // (R,4) rows [r,g,b,depth]: the gather buffer
+            } else {
+                a.rgb[own_rid * 3 + 0] = r;
+                a.rgb[own_rid * 3 + 1] = g;
+                a.rgb[own_rid * 3 + 2] = b;
+                a.depth[own_rid] = comp.depth;
+            }
         }
     }
     pipe.drain();
@@ -434,10 +466,14 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
                         const float bg = __fsub_rn(1.0f, comp.acc);
                         r = __fadd_rn(r, bg); g = __fadd_rn(g, bg); b = __fadd_rn(b, bg);
                     }
-                    a.rgb[rr * 3 + 0] = r;
-                    a.rgb[rr * 3 + 1] = g;
-                    a.rgb[rr * 3 + 2] = b;
-                    a.depth[rr] = comp.depth;
+                    if (a.interleaved) {
+                        *(float4*)(a.rgb + rr * 4) = make_float4(r, g, b, comp.depth);
+                    } else {
+                        a.rgb[rr * 3 + 0] = r;
+                        a.rgb[rr * 3 + 1] = g;
+                        a.rgb[rr * 3 + 2] = b;
+                        a.depth[rr] = comp.depth;
+                    }
                 }
                 ray = -1;
             } else {
@@ -591,6 +627,24 @@ NetArgs net_args(const DeviceNet& net, int mode) {
     return n;
 }
 
+// Samples per ray and pass (log2; render_kernel): the work items of a launch are tiles of WAVES * 32/SPW rays marched in
+// ceil(S/SPW) passes, dealt to the CUs in whole rounds -- pick the SPW in {1,2,4} with the least rounds x passes (the
+// wider composite costs ~1 % per doubling; ties go to the smaller SPW).  NRF_SPW=0|1|2 pins it (A/B runs; any value is exact).
+inline int pick_spw_log2(int64_t n_rays, int S, int waves, int cu) {
+    static const int pinned = [] { const char* e = getenv("NRF_SPW"); return e ? atoi(e) : -1; }();
+    if (pinned >= 0 && pinned <= 2) return pinned;
+    int best = 0;
+    double best_t = 0.0;
+    for (int l = 0; l <= 2; ++l) {
+        const int64_t tile = (int64_t)waves * (32 >> l);
+        const int64_t tiles = (n_rays + tile - 1) / tile;
+        const int64_t rounds = (tiles + cu - 1) / cu;
+        const double t = (double)rounds * (double)((S + (1 << l) - 1) >> l) * (1.0 + 0.01 * l);
+        if (l == 0 || t < best_t * (1.0 - 1e-9)) { best_t = t; best = l; }
+    }
+    return best;
+}
+
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
 int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
     auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD, ERT>;
@@ -600,8 +654,9 @@ int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_
     RenderKArgs k;
     k.net = net_args(net, mode);
     k.a = a;
-    constexpr int TILE = WAVES * 32 * NT;
-    k.n_tiles = (a.n_rays + TILE - 1) / TILE;
+    k.a.spw_log2 = (NT == 1 && !ERT) ? pick_spw_log2(a.n_rays, a.n_samples, WAVES, net.cu_count) : 0;
+    const int64_t tile = (int64_t)WAVES * NT * (32 >> k.a.spw_log2);
+    k.n_tiles = (a.n_rays + tile - 1) / tile;
     const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
     const hipError_t e = hipGetLastError();

@@ -59,12 +59,14 @@ struct RenderArgs {
     float ert_eps;
     int white_bkgd;
     // outputs
+    int interleaved;        // 1: rgb points at (R,4) rows [r,g,b,depth] (one 16-B store per ray), depth is unused
     float* rgb;
     float* depth;
     float* weights;
     float* z_vals;
     DinoDev dino;
     unsigned long long* queue;   // ERT (ray-queue) kernel: device counter of rays handed out, zeroed before the launch
+    int spw_log2;                // render_kernel: log2 of the samples per ray and MLP pass (set by the launcher)
 };
 
 int launch_render(const DeviceNet& net, int mma_mode, const RenderArgs& a, hipStream_t s, std::string& err);

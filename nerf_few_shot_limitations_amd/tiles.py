@@ -68,7 +68,7 @@ def _poses12(c2w) -> "C.Array":
 
 class TileJob:
     """Everything one rank needs to render its tiles of a batch of views, prepared once:
-    `launch()` enqueues exactly the render kernel(s); `pack()` interleaves rgb+depth into the gather buffer."""
+    `launch()` enqueues exactly the render kernel(s), which write rgb+depth rows straight into the gather buffer `buf`."""
 
     def __init__(self, model, H, W, focal, c2w, near, far, N_samples, rank, world, tile_rays, perturb=False, seed=0, lindisp=False,
                  ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, device=None):
@@ -91,9 +91,8 @@ class TileJob:
         self.model = model
         self.poses, self.V = _poses12(c2w)
         self.n_real = len(range(self.rank, self.tiles_total, self.world))   # tiles that start inside the image; the rest is padding
+        self.opts.out_rgbd = 1                                               # the kernel writes [r,g,b,depth] rows: no packing pass
         with torch.cuda.device(self.device):
-            self.rgb = torch.empty((self.V, self.n_real * self.tile_rays, 3), dtype=torch.float32, device=self.device)
-            self.depth = torch.empty((self.V, self.n_real * self.tile_rays), dtype=torch.float32, device=self.device)
             self.buf = torch.zeros((self.V, self.per_rank * self.tile_rays, 4), dtype=torch.float32, device=self.device)
 
     @property
@@ -101,20 +100,26 @@ class TileJob:
         return min(8, self.V) * self.n_real * self.tile_rays
 
     def launch(self):
+        """Enqueue the render kernel(s): they write this rank's tiles straight into the gather buffer `self.buf`
+        (V, per_rank*tile_rays, 4).  One launch per 8 views when the tiles deal evenly (every rank's buffer is all real tiles);
+        otherwise one launch per view, each into the real-tile prefix of that view's rows (the padding rows stay zero)."""
         h = self.model.handle(self.device, self.mma_mode)
+        n = self.n_real * self.tile_rays
+        if n == 0:
+            return
+        even = self.n_real == self.per_rank
+        step = 8 if even else 1
         with torch.cuda.device(self.device):
-            for v0 in range(0, self.V, 8):
-                nv = min(8, self.V - v0)
+            for v0 in range(0, self.V, step):
+                nv = min(step, self.V - v0)
                 sub = (C.c_float * (12 * nv)).from_buffer(self.poses, 4 * 12 * v0)
+                out = self.buf[v0:v0 + nv] if even else self.buf[v0, :n]
                 L.check(L.lib().nrf_render_cameras_tiles(h, self.H, self.W, self.focal, C.cast(sub, C.c_void_p), nv, self.tile_rays,
                                                          self.rank, self.world, self.n_real, C.byref(self.opts),
-                                                         L.ptr(self.rgb[v0:v0 + nv]), L.ptr(self.depth[v0:v0 + nv]), None, None,
-                                                         L.stream_ptr()))
+                                                         L.ptr(out), None, None, None, L.stream_ptr()))
 
     def pack(self):
-        n = self.n_real * self.tile_rays
-        self.buf[:, :n, :3] = self.rgb
-        self.buf[:, :n, 3] = self.depth
+        """The gather buffer (kept for callers of the round-1 interface: the kernel has already written it)."""
         return self.buf
 
 

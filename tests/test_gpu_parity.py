@@ -14,6 +14,9 @@ from oracle import nerf_oracle as O
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-4
+# the two parity-grade arithmetic modes: exact fp32 MFMA (1/16 rate) and the split-f16 mode (3 MFMAs per product at the 16-bit
+# rate); both must meet the fp32 bar everywhere
+PARITY = ["f32", "f16x3"]
 
 
 def T(a):
@@ -152,7 +155,7 @@ def test_composite_kats(N, golden):
 
 
 # ------------------------------------------------------------------ MFMA operand layout: exact integer data
-@pytest.mark.parametrize("mode", ["f32", "f16", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "f16x3", "f16", "bf16"])
 @pytest.mark.parametrize("n_layers", [1, 2, 3])
 def test_mlp_layout_exact_integers(N, mode, n_layers):
     """Small-integer, ASYMMETRIC, sparse weights and inputs: every product and partial sum is exactly
@@ -187,10 +190,11 @@ def test_mlp_layout_exact_integers(N, mode, n_layers):
 
 
 # ------------------------------------------------------------------ a5 V1 MLP vs golden
+@pytest.mark.parametrize("pmode", PARITY)
 @pytest.mark.parametrize("scene", ["fog", "solid"])
-def test_mlp_v1_golden_f32(N, golden, scene):
+def test_mlp_v1_golden_f32(N, golden, scene, pmode):
     g = golden(f"mlp_v1_{scene}")
-    m, _ = model_v1(N, scene, "f32")
+    m, _ = model_v1(N, scene, pmode)
     with torch.no_grad():
         out = m(T(g["x_enc"]))
     assert maxdiff(out[:, :3], g["out"][:, :3]) <= 1e-5
@@ -209,10 +213,12 @@ def test_mlp_v1_golden_16bit(N, golden, mode, tol):
 def test_mlp_v2_golden(N, golden):
     g = golden("mlp_v2")
     m, _ = model_v2(N, "fog", "f32")
-    with torch.no_grad():
-        rgb, dens = m(T(g["pos"]), T(g["dirs"]), None)
-    assert rgb.shape == (g["pos"].shape[0], 3) and dens.shape == (g["pos"].shape[0], 1)
-    assert maxdiff(rgb, g["rgb"]) <= 1e-5 and maxdiff(dens, g["density"]) <= 1e-5
+    for pmode in PARITY:
+        m.mma_mode = pmode
+        with torch.no_grad():
+            rgb, dens = m(T(g["pos"]), T(g["dirs"]), None)
+        assert rgb.shape == (g["pos"].shape[0], 3) and dens.shape == (g["pos"].shape[0], 1)
+        assert maxdiff(rgb, g["rgb"]) <= 1e-5 and maxdiff(dens, g["density"]) <= 1e-5
     for mode, tol in (("f16", 6e-3), ("bf16", 8e-2)):                        # measured 2.1e-3 / 2.5e-2
         m.mma_mode = mode
         with torch.no_grad():
@@ -220,10 +226,11 @@ def test_mlp_v2_golden(N, golden):
         assert maxdiff(rgb, g["rgb"]) <= tol and maxdiff(dens, g["density"]) <= tol
 
 
-def test_mlp_v3_golden(N, golden):
+@pytest.mark.parametrize("pmode", PARITY)
+def test_mlp_v3_golden(N, golden, pmode):
     """NeRFWithDINO (nerf_mlp.py:134-158) incl. the twice-run fusion block and its softmax gate."""
     g = golden("mlp_v3")
-    m, _ = model_v3(N, "fog", "f32")
+    m, _ = model_v3(N, "fog", pmode)
     with torch.no_grad():
         rgb, dens = m(T(g["pos"]), T(g["dirs"]), T(g["dino"]))
     assert maxdiff(rgb, g["rgb"]) <= 2e-5 and maxdiff(dens, g["density"]) <= 2e-5 * max(1.0, float(g["density"].max()))
@@ -234,10 +241,11 @@ def test_mlp_v3_golden(N, golden):
         assert maxdiff(rgb, g["rgb"]) <= tol
 
 
-def test_mlp_v3_multiscale_width(N, golden):
+@pytest.mark.parametrize("pmode", PARITY)
+def test_mlp_v3_multiscale_width(N, golden, pmode):
     """experiments/multiscale.yaml: 128-d features (multi_scale_dino.py:50) -> four feature tiles."""
     g = golden("mlp_v3_d128")
-    m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=128, mma_mode="f32")
+    m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=128, mma_mode=pmode)
     m.load_state_dict(O.make_weights("v3", 3, dino_dim=128), strict=False)
     m = m.cuda().eval()
     with torch.no_grad():
@@ -246,13 +254,14 @@ def test_mlp_v3_multiscale_width(N, golden):
     assert m.flops_per_sample() == 2 * (918976 + 2 * 256 * 64)      # SURVEY a7 MAC count + the wider fusion.0 run twice
 
 
-def test_render_v3_end_to_end_golden(N, golden):
+@pytest.mark.parametrize("pmode", PARITY)
+def test_render_v3_end_to_end_golden(N, golden, pmode):
     """Config C4 path: project each sample into the source view, bilinear fetch of the feature map, fusion, trunk,
     colour, composite -- one kernel -- against the reference's outputs (train.py:203-242)."""
     g = golden("end_to_end")
     H, W, S = int(g["H"]), int(g["W"]), int(g["S"])
     ro, rd = N.get_rays(H, W, float(g["focal"]), T(g["c2w"]))
-    m, _ = model_v3(N, "fog", "f32")
+    m, _ = model_v3(N, "fog", pmode)
     dino = dict(features=dino_map(), pose=T(g["c2w"]), focal=float(g["focal"]), H=H, W=W)
     for tag, tr in (("plain", None), ("jit", T(g["t_rand"]))):
         out = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=tr, dino=dino)
@@ -276,6 +285,30 @@ def test_model_update_repacks(N, golden):
     assert maxdiff(b[:, :3], golden("mlp_v1_solid")["out"][:, :3]) <= 1e-5
 
 
+def test_split_mode_device_repack_equals_host_pack(N, golden):
+    """nrf_model_update_device in the split mode (hi / lo parts converted on the device, train_v1.hip:convert_pair) produces
+    the very stream the host packer builds (packing.cpp:pack_stream): same outputs to the last bit.  Also: a module in the
+    split mode trains through the exact-fp32 training kernels (_lib.TRAIN_MODE)."""
+    g = golden("mlp_v1_fog")
+    x = T(g["x_enc"])
+    for mode in ("f16x3", "f16"):
+        m, _ = model_v1(N, "fog", mode)
+        with torch.no_grad():
+            a = m(x)                                   # streams packed on the host at model creation
+        m.flat_params().ensure()                       # parameters become views of one flat device vector ...
+        m._gen += 1                                    # ... and the next handle() re-packs from it on the device
+        with torch.no_grad():
+            b = m(x)
+        assert torch.equal(a, b), mode
+    m, p = model_v1(N, "fog", "f16x3")
+    out = m.train()(x[:64].cuda())
+    out.sum().backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in m.parameters())
+    with torch.no_grad():
+        c = m.eval()(x)                                 # after the training-mode pass the split stream is still current
+    assert maxdiff(c, g["out"]) <= 1e-5
+
+
 def test_forward_under_grad_is_differentiable_or_refuses(N):
     """Every NeRFMLP form runs the training kernels under grad (tests/test_gpu_training.py); what has no backward -- the
     DINO features' own gradient -- is refused instead of silently detached."""
@@ -290,13 +323,14 @@ def test_forward_under_grad_is_differentiable_or_refuses(N):
 
 
 # ------------------------------------------------------------------ a11 fused renderer vs golden (reference outputs)
+@pytest.mark.parametrize("pmode", PARITY)
 @pytest.mark.parametrize("variant", ["v1", "v2"])
-def test_render_end_to_end_golden_f32(N, golden, variant):
+def test_render_end_to_end_golden_f32(N, golden, variant, pmode):
     g = golden("end_to_end")
     H, W, S = int(g["H"]), int(g["W"]), int(g["S"])
     ro, rd = N.get_rays(H, W, float(g["focal"]), T(g["c2w"]))
     for scene in ("fog", "solid"):
-        m, _ = (model_v1 if variant == "v1" else model_v2)(N, scene, "f32")
+        m, _ = (model_v1 if variant == "v1" else model_v2)(N, scene, pmode)
         for tag, tr in (("plain", None), ("jit", T(g["t_rand"]))):
             out = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=tr, return_z=True)
             assert maxdiff(out["rgb"], g[f"{variant}_{scene}_{tag}_rgb"]) <= TOL
@@ -316,11 +350,12 @@ def test_render_end_to_end_golden_16bit(N, golden, mode, tol):
 
 
 # ------------------------------------------------------------------ fused renderer vs oracle at C1-like size; properties at full size
-def test_render_vs_oracle_100x100x32(N):
+@pytest.mark.parametrize("pmode", PARITY)
+def test_render_vs_oracle_100x100x32(N, pmode):
     """BASELINE.json configs[0]: 100x100, 32 samples -- the CPU-runnable case, rendered by both paths."""
     H = W = 100; S = 32
     c2w = T(O.LEGO_LIKE_C2W)
-    m, p = model_v1(N, "solid", "f32")
+    m, p = model_v1(N, "solid", pmode)
     rgb, depth = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
     ro, rd = O.get_rays(H, W, O.focal_for(W), c2w)
     ref = O.render_rays(p, "v1", ro, rd, 2.0, 6.0, S)
@@ -345,7 +380,7 @@ def test_render_vs_oracle_100x100x32(N):
 def test_camera_mode_equals_explicit_rays_bitwise(N):
     H, W, S = 37, 53, 16                                    # odd sizes: ragged last tile
     c2w = T(O.LEGO_LIKE_C2W)
-    for mode in ("f32", "bf16"):
+    for mode in ("f32", "f16x3", "bf16"):
         m, _ = model_v1(N, "solid", mode)
         ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
         a = N.render_rays(m, ro, rd, 2.0, 6.0, S)
@@ -387,6 +422,65 @@ def test_round_robin_tiles_and_view_batches_reassemble_bitwise(N):
     assert torch.equal(rgb.reshape(-1, 3), full[0][0]) and torch.equal(depth.reshape(-1), full[0][1])
 
 
+@pytest.mark.parametrize("shape", [(48, 40, 16, 4, "bf16"), (50, 36, 8, 4, "f16x3")])      # even deal / ragged (padding tiles, per-view launches)
+def test_two_process_tile_render_and_gather(N, shape, tmp_path):
+    """The N>1 path end to end in TWO processes (tests/tiles_worker.py, launched like bench.py --gpus 2): TileJob.launch (kernel
+    writes [r,g,b,depth] rows into the gather buffer) -> gather_frames (one all_gather; gloo here because both ranks share the
+    test box's one GPU, RCCL on a real node) -> every rank holds every frame, bitwise equal to single-process render_camera."""
+    import os, socket, subprocess, sys
+    H, W, S, tile_rows, mode = shape
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "tiles_worker.py"), str(tmp_path), str(H), str(W), str(S), str(tile_rows), mode]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("tiles_worker", os.path.join(os.path.dirname(__file__), "tiles_worker.py"))
+    worker = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(worker)
+    poses = worker.scene()
+    m, _ = model_v1(N, "solid", mode)
+    for rank in range(2):
+        frames = np.load(os.path.join(str(tmp_path), f"frames_rank{rank}.npy"))
+        assert frames.shape == (2, H * W, 4)
+        for v in range(2):
+            rgb, depth = N.render_camera(m, H, W, O.focal_for(W), poses[v], 2.0, 6.0, S)
+            assert np.array_equal(frames[v, :, :3], rgb.cpu().numpy()) and np.array_equal(frames[v, :, 3], depth.cpu().numpy()), (rank, v)
+
+
+def test_rgbd_rows_equal_separate_outputs_and_work_split_is_invisible(N):
+    """(a) nrf_render_opts.out_rgbd: the (R,4) [r,g,b,depth] rows the tile jobs write equal the separate outputs bit for bit;
+    (b) the samples-per-pass split of a launch (render_kernel: 32 rays x 1 sample, 16 x 2 or 8 x 4 per wave and pass, picked
+    from the ray count) never changes a bit: an 80 000-ray launch (split 4), its first 40 000 rays alone and 300-ray pieces
+    agree, with weights and depths, for odd sample counts too."""
+    from nerf_few_shot_limitations_amd import tiles
+    c2w = T(O.LEGO_LIKE_C2W)
+    H, W, S = 64, 80, 16
+    m, _ = model_v1(N, "solid", "bf16")
+    job = tiles.TileJob(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, 0, 1, 16 * W)
+    job.launch()
+    rgb, depth = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
+    assert torch.equal(job.buf[0, :, :3], rgb) and torch.equal(job.buf[0, :, 3], depth)
+    for mode, S in (("bf16", 13), ("f16x3", 6)):
+        m, _ = model_v1(N, "solid", mode)
+        Hb, Wb = 200, 400                                               # 80 000 rays
+        ro, rd = N.get_rays(Hb, Wb, O.focal_for(Wb), c2w)
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        full = N.render_rays(m, ro, rd, 2.0, 6.0, S, return_z=True)
+        half = N.render_rays(m, ro[:40000], rd[:40000], 2.0, 6.0, S, return_z=True)
+        for k in ("rgb", "depth", "weights", "z_vals"):
+            assert torch.equal(full[k][:40000], half[k]), (mode, k)
+        for b in (0, 30011, 79700):
+            piece = N.render_rays(m, ro[b:b + 300], rd[b:b + 300], 2.0, 6.0, S, return_z=True)
+            for k in ("rgb", "depth", "weights", "z_vals"):
+                assert torch.equal(full[k][b:b + 300], piece[k]), (mode, k, b)
+        cam = N.render_camera(m, Hb, Wb, O.focal_for(Wb), c2w, 2.0, 6.0, S)
+        assert torch.equal(cam[0], full["rgb"]) and torch.equal(cam[1], full["depth"])
+
+
 def test_early_ray_termination_bounds(N):
     H = W = 64; S = 64
     c2w = T(O.LEGO_LIKE_C2W)
@@ -408,7 +502,7 @@ def test_ray_queue_kernel_matches_tile_kernel(N, variant):
     Ragged ray counts, explicit rays + weights/z outputs, camera mode, and the fp32 geometry (4 waves) are covered."""
     mk = model_v1 if variant == "v1" else model_v2
     c2w = T(O.LEGO_LIKE_C2W)
-    for mode in ("bf16", "f32"):
+    for mode in ("bf16", "f32", "f16x3"):
         m, _ = mk(N, "solid", mode)
         for (H, W, S) in ((37, 53, 16), (8, 9, 40)):
             ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
@@ -479,29 +573,32 @@ def test_full_frame_properties_800x800x64(N):
     ro, rd = O.get_rays(H, W, O.focal_for(W), c2w)
     ref = O.render_rays(p, "v1", ro.reshape(-1, 3)[b0:b1], rd.reshape(-1, 3)[b0:b1], 2.0, 6.0, S)
     assert O.psnr(band_rgb.cpu(), ref["rgb"]) > 25                  # bf16 frame vs fp32 oracle (see the tail-rule note above)
-    m32, _ = model_v1(N, "solid", "f32")
-    r32, d32 = N.render_camera(m32, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ray_begin=b0, ray_end=b1)
-    assert maxdiff(r32, ref["rgb"]) <= TOL and maxdiff(d32, ref["depth"]) <= TOL
+    for pmode in PARITY:
+        m32, _ = model_v1(N, "solid", pmode)
+        r32, d32 = N.render_camera(m32, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ray_begin=b0, ray_end=b1)
+        assert maxdiff(r32, ref["rgb"]) <= TOL and maxdiff(d32, ref["depth"]) <= TOL
 
 
+@pytest.mark.parametrize("pmode", PARITY)
 @pytest.mark.parametrize("S", [2, 192])
-def test_render_sample_count_extremes(N, S):
-    """S=2 (one interval + the 1e10 tail) and S=192 (the fine pass of config 3) against the oracle, fp32 mode."""
+def test_render_sample_count_extremes(N, S, pmode):
+    """S=2 (one interval + the 1e10 tail) and S=192 (the fine pass of config 3) against the oracle, parity modes."""
     H, W = 9, 31
     c2w = T(O.LEGO_LIKE_C2W)
-    m, p = model_v1(N, "fog", "f32")
+    m, p = model_v1(N, "fog", pmode)
     rgb, depth = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
     ro, rd = O.get_rays(H, W, O.focal_for(W), c2w)
     ref = O.render_rays(p, "v1", ro, rd, 2.0, 6.0, S)
     assert maxdiff(rgb, ref["rgb"]) <= TOL and maxdiff(depth, ref["depth"]) <= TOL
 
 
-def test_render_lindisp_white_background_and_shallow_nets(N):
+@pytest.mark.parametrize("pmode", PARITY)
+def test_render_lindisp_white_background_and_shallow_nets(N, pmode):
     H, W, S = 11, 13, 24
     c2w = T(O.LEGO_LIKE_C2W)
     ro, rd = O.get_rays(H, W, O.focal_for(W), c2w)
     # lindisp sampling (ray_utils.py:59-62) + white background (nerf_mlp.py:209-212)
-    m, p = model_v1(N, "fog", "f32")
+    m, p = model_v1(N, "fog", pmode)
     out = N.render_rays(m, ro, rd, 2.0, 6.0, S, lindisp=True, white_bkgd=True, return_z=True)
     with torch.no_grad():
         pts, z = O.sample_points_along_rays(ro.reshape(-1, 3), rd.reshape(-1, 3), 2.0, 6.0, S, lindisp=True)
@@ -510,12 +607,12 @@ def test_render_lindisp_white_background_and_shallow_nets(N):
     assert maxdiff(out["z_vals"], z) <= 1e-6
     assert maxdiff(out["rgb"], c) <= TOL and maxdiff(out["depth"], dep) <= TOL and maxdiff(out["weights"], w) <= TOL
     # trunks of other depths walk the even/odd buffer paths of the kernel (nets.hpp): V1 with 5 layers, V2 with 3 and 4
-    m5, p5 = model_v1(N, "fog", "f32", n_layers=5)
+    m5, p5 = model_v1(N, "fog", pmode, n_layers=5)
     ref = O.render_rays(p5, "v1", ro, rd, 2.0, 6.0, S)
     out = N.render_rays(m5, ro, rd, 2.0, 6.0, S)
     assert maxdiff(out["rgb"], ref["rgb"]) <= TOL and maxdiff(out["depth"], ref["depth"]) <= TOL
     for nl in (3, 4):
-        mv = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=nl, use_dino=False, mma_mode="f32")
+        mv = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=nl, use_dino=False, mma_mode=pmode)
         pv = O.make_weights("v2", 5, "fog", n_layers=nl)
         mv.load_state_dict(pv, strict=False)
         mv = mv.cuda().eval()
@@ -543,11 +640,12 @@ def test_internal_jitter_is_keyed_by_global_ray_id(N):
     assert torch.equal(frame[:, :3], a[0]) and torch.equal(frame[:, 3], a[1])
 
 
-def test_trainer_shaped_surface(N):
+@pytest.mark.parametrize("pmode", PARITY)
+def test_trainer_shaped_surface(N, pmode):
     """NeRFRenderer.render_rays(rays_o, rays_d, view_idx, N_samples) / render_full_image(...) (train.py:188, evaluate.py:65)."""
     H, W = 16, 16
     c2w = T(O.LEGO_LIKE_C2W)
-    m, p = model_v2(N, "fog", "f32")
+    m, p = model_v2(N, "fog", pmode)
     r = N.NeRFRenderer(m, 2.0, 6.0)
     ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
     out = r.render_rays(ro.view(-1, 3), rd.view(-1, 3), 0, 32)
@@ -683,14 +781,15 @@ def test_sample_pdf_vs_oracle(N):
     assert torch.all(union[:, 1:] >= union[:, :-1])
 
 
-def test_hierarchical_render_c3(N):
+@pytest.mark.parametrize("pmode", PARITY)
+def test_hierarchical_render_c3(N, pmode):
     """BASELINE.json config 3 shape (coarse + importance samples, sorted union, fine pass) at a size the oracle
     finishes in seconds.  The resampling step's parity is unpinned (the reference function raises); the fine pass is
     checked against the oracle ON THE SAME union depths, the union against the oracle's own resampling."""
     H, W = 24, 20
     S, Ni = 32, 16
     c2w = T(O.LEGO_LIKE_C2W)
-    m, p = model_v1(N, "solid", "f32")
+    m, p = model_v1(N, "solid", pmode)
     ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
     out = N.render_hierarchical(m, ro, rd, 2.0, 6.0, S, Ni)
     assert out["z_vals"].shape == (H * W, S + Ni) and out["weights"].shape == (H * W, S + Ni)

@@ -22,7 +22,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import nerf_few_shot_limitations_amd as N                       # noqa: E402
 from oracle import nerf_oracle as O                             # noqa: E402  (synthetic weights / camera generators only)
 
-PEAK = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3}
+PEAK = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x3": 2500.0}
 
 
 def timed(fn, reps):
@@ -37,7 +37,7 @@ def timed(fn, reps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32", "f16x3"])
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -61,6 +61,8 @@ def main():
         ("C3 800x800 128 coarse + 64 fine (hierarchical)", lambda: N.render_hierarchical(v2, ro8, rd8, 2.0, 6.0, 128, 64), 800 * 800 * (128 + 192), v2),
         ("C4 400x400x64 DINO-conditioned", camera(v3, 400, 64, dict(features=fm, pose=c2w, focal=O.focal_for(400), H=400, W=400)), 400 * 400 * 64, v3),
         ("C5 800x800x128 baseline, one GPU", camera(v2, 800, 128), 800 * 800 * 128, v2),
+        ("C5 shard: 100 rows (80 000 rays) x 128 of the 800x800 frame = one GPU's share of 8", lambda: N.render_camera(v2, 800, 800, O.focal_for(800), c2w, 2.0, 6.0, 128, ray_begin=0, ray_end=80000), 80000 * 128, v2),
+        ("headline shape 800x800x64 baseline", camera(v2, 800, 64), 800 * 800 * 64, v2),
     ]
     with torch.no_grad():
         for name, fn, samples, model in cases:

@@ -163,8 +163,10 @@ int nrf_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_ra
                           float near, float far, int n_samples, int lindisp, int perturb,
                           const float* t_rand, const float* z_ladder, uint64_t rng_seed,
                           float* pts, float* z_vals, void* stream);
-/* positional_encoding.py:20-33 == nerf_mlp.py:17-33.  x (n,dim) -> out (n, dim*(2L+include_input)). */
-int nrf_encode(const float* x, int64_t n, int dim, int num_freqs, int include_input, float* out, void* stream);
+/* positional_encoding.py:20-33 == nerf_mlp.py:17-33.  x (n,dim) -> out (n, dim*(2L+include_input)).
+ * freq_bands: NULL = 2^k, k = 0..L-1 (log_sampling=True, every caller of the reference), or a device table of L
+ * frequencies (log_sampling=False, positional_encoding.py:18: torch.linspace(1, 2^(L-1), L) as the caller computed it). */
+int nrf_encode(const float* x, int64_t n, int dim, int num_freqs, int include_input, const float* freq_bands, float* out, void* stream);
 /* V1: nerf_model.py:16-24, x_enc (P, 3*(2*pos_freq+1)) -> out4 (P,4) = [rgb, sigma]. */
 int nrf_mlp_forward_v1(const nrf_model* m, int mma_mode, const float* x_enc, int64_t n, float* out4, void* stream);
 /* V2/V3: NeRFMLP.forward(positions, directions, dino_features), train.py:229 / nerf_mlp.py:134-158:

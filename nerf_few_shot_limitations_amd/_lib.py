@@ -67,7 +67,7 @@ SIGNATURES = {
     "nrf_get_rays": (C.c_int, [C.c_int, C.c_int, C.c_float, C.c_float * 12, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_sample_along_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int,
                                         C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "nrf_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "nrf_encode": (C.c_int, [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_mlp_forward_v1": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "nrf_mlp_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_composite": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
@@ -143,6 +143,21 @@ def dev_f32(t, device=None):
     if device is None:
         device = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def refuse_grad(t, what):
+    """The staged leaf kernels produce no gradient with respect to their inputs (the reference never needs one: positions,
+    directions, rays and depths are data).  Under grad mode a tensor that requires grad is refused -- as NeRFMLP.forward refuses
+    DINO features that require grad -- instead of being detached silently."""
+    if torch.is_grad_enabled() and isinstance(t, torch.Tensor) and t.requires_grad:
+        raise NotImplementedError(f"{what}: no gradient with respect to this input is produced; pass it detached or call under torch.no_grad()")
+    return t
+
+
+def fresh_seed():
+    """A new seed for the in-kernel jitter RNG, drawn from torch's default CPU generator: a fresh pattern on every call (the
+    reference draws torch.rand per call, ray_utils.py:78) that repeats under torch.manual_seed."""
+    return int(torch.randint(0, 2 ** 62, (), dtype=torch.int64).item())
 
 
 def stream_ptr():

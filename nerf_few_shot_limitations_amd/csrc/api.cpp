@@ -393,11 +393,11 @@ int nrf_sample_along_rays(const float* rays_o, const float* rays_d, int64_t n_ra
     return r == NRF_OK ? NRF_OK : fail(r, "sample launch failed");
 }
 
-int nrf_encode(const float* x, int64_t n, int dim, int num_freqs, int include_input, float* out, void* stream) {
-    if (n < 0 || dim < 1 || num_freqs < 0 || num_freqs > 31) return fail(NRF_EINVAL, "bad sizes");
+int nrf_encode(const float* x, int64_t n, int dim, int num_freqs, int include_input, const float* freq_bands, float* out, void* stream) {
+    if (n < 0 || dim < 1 || num_freqs < 0 || (num_freqs > 31 && !freq_bands)) return fail(NRF_EINVAL, "bad sizes");
     if (n == 0) return NRF_OK;
     if (!x || !out) return fail(NRF_EINVAL, "null pointer");
-    const int r = nrf::launch_encode(x, n, dim, num_freqs, include_input, out, (hipStream_t)stream);
+    const int r = nrf::launch_encode(x, n, dim, num_freqs, include_input, freq_bands, out, (hipStream_t)stream);
     return r == NRF_OK ? NRF_OK : fail(r, "encode launch failed");
 }
 

@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 // Both lanes of a pair run the identical compositor (the head tile carries [r,g,b,sigma] for both halves), so they
 // agree on termination without exchanging anything; only the low lane stores.  Per-ray arithmetic is exactly that of
 // render_kernel, so with ert_eps -> 0 the image is the same; with ert_eps > 0 each ray stops at ITS OWN T < eps.
-constexpr int kStrip = 128;
+constexpr int kStrip = 32;        // rays handed out per atomic: one wave-load, so that the frame's last strips spread over all waves (128 left a 4-batch tail: +18 %)
 constexpr int kLadderLds = 1024;      // depth-ladder entries cached in LDS (per-lane sample indices gather from it)
 
 template <class Net, class Mode, int WAVES, int LP, int LD>
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     ST(F_OX) = 0.f; ST(F_OY) = 0.f; ST(F_OZ) = 0.f; ST(F_DX) = 0.f; ST(F_DY) = 0.f; ST(F_DZ) = -1.f; ST(F_Z) = 1.f;
     load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
 
-    Pipe<WAVES, true> pipe;
+    Pipe<WAVES, false> pipe;     // a wave that has run dry keeps computing (on stale inputs, storing nothing): the workgroup moves in lockstep anyway, and the skip paths cost registers in every layer
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 

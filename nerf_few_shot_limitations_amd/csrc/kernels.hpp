@@ -121,7 +121,7 @@ int launch_composite_backward(const float* rgb, int rgb_stride, const float* sig
 int launch_get_rays(const Camera& cam, int64_t ray_begin, int64_t n, float* rays_o, float* rays_d, hipStream_t s);
 int launch_sample(const float* rays_o, const float* rays_d, int64_t n_rays, float near, float far, int S, int lindisp,
                   int perturb, const float* t_rand, const float* z_ladder, uint64_t seed, float* pts, float* z_vals, hipStream_t s);
-int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, float* out, hipStream_t s);
+int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, const float* freq_bands, float* out, hipStream_t s);
 int launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
                      int64_t n_rays, int S, int white_bkgd, float* out_rgb, float* out_depth, float* out_w, hipStream_t s);
 int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, float* samples,

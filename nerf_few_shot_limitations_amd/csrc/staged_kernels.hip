@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(kBlock) sample_kernel(const float* __restrict_
 
 // ---- a4: positional_encoding.py:20-33 ------------------------------------------------------
 __global__ void __launch_bounds__(kBlock) encode_kernel(const float* __restrict__ x, int64_t n, int dim, int L, int include_input,
-                                                        float* __restrict__ out) {
+                                                        const float* __restrict__ freq_bands, float* __restrict__ out) {
     const int d_out = dim * (2 * L + (include_input ? 1 : 0));
     const int64_t total = n * d_out;
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
@@ -69,7 +69,9 @@ __global__ void __launch_bounds__(kBlock) encode_kernel(const float* __restrict_
             const int band = f / (2 * dim);
             const int rem = f - band * 2 * dim;
             const int j = rem >= dim ? rem - dim : rem;
-            const float arg = __fmul_rn(x[row * dim + j], (float)(1u << band));   // exact: power-of-two scale
+            // log_sampling (every caller of the reference): 2^band, an exact scale; otherwise the caller's table
+            // (positional_encoding.py:18: torch.linspace(1, 2^(L-1), L))
+            const float arg = __fmul_rn(x[row * dim + j], freq_bands ? freq_bands[band] : (float)(1u << band));
             v = rem >= dim ? cosf(arg) : sinf(arg);
         }
         out[i] = v;
@@ -236,65 +238,119 @@ __global__ void __launch_bounds__(kBlock) composite_backward_kernel(const float*
 }
 
 // ---- a3: ray_utils.py:86-143 (intent) --------------------------------------------------------
-// one thread per ray; its cdf (S+1) and new samples (Ni) live in a private LDS row
+// One WAVE per ray, LANE <-> sample: the rows of z, weights, the new samples and the union are read and written as contiguous
+// 64-element segments; the cdf is a wave prefix sum; every search (inverse cdf, merge ranks) is a branch-free binary search over
+// the wave's private LDS rows.  HBM-bound: 8 S + 4 Ni + 4 (S + Ni) bytes per ray.  The coarse depths z must ascend (they are a
+// depth ladder); the new samples may arrive in any order (perturbed u) and are ranked before the merge.
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const float u = __shfl_up(v, d, 64);
+        if (lane >= d) v = __fadd_rn(v, u);
+    }
+    return v;
+}
+// number of leading elements of the ascending row a[0..n) that are <= x (upper bound) / < x (lower bound)
+__device__ __forceinline__ int count_le(const float* a, int n, int top, float x) {
+    int pos = 0;
+    for (int step = top; step > 0; step >>= 1)
+        if (pos + step <= n && a[pos + step - 1] <= x) pos += step;
+    return pos;
+}
+__device__ __forceinline__ int count_lt(const float* a, int n, int top, float x) {
+    int pos = 0;
+    for (int step = top; step > 0; step >>= 1)
+        if (pos + step <= n && a[pos + step - 1] < x) pos += step;
+    return pos;
+}
+__host__ __device__ inline int top_pow2(int n) { int t = 1; while (t * 2 <= n) t *= 2; return t; }
+
 __global__ void sample_pdf_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t n_rays, int S, int Ni,
                                   const float* __restrict__ u_in, float* __restrict__ samples, float* __restrict__ z_union) {
     extern __shared__ float lds_rows[];
-    const int row_len = S + 1 + Ni;
-    float* cdf = lds_rows + (size_t)threadIdx.x * row_len;
-    float* smp = cdf + S + 1;
-    const int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (r >= n_rays) return;
-    const float* zr = z + r * S;
-    const float* wr = w + r * S;
-    float total = 0.0f;
-    for (int s = 0; s < S; ++s) total = __fadd_rn(total, __fadd_rn(wr[s], 1e-5f));       // sum(weights + 1e-5)   (:104,:107)
-    cdf[0] = 0.0f;
-    float run = 0.0f;
-    for (int s = 0; s < S; ++s) {                                                        // cumsum(pdf)           (:108-109)
-        run = __fadd_rn(run, __fadd_rn(wr[s], 1e-5f) / total);
-        cdf[s + 1] = run;
-    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row_len = 3 * S + 3 * Ni + 1;
+    float* cdf = lds_rows + (size_t)wave * row_len;         // S + 1 knots
+    float* zl = cdf + S + 1;                                // S coarse depths
+    float* smp = zl + S;                                    // Ni new samples, in the order of u
+    float* ssort = smp + Ni;                                // Ni new samples, ascending
+    float* uni = ssort + Ni;                                // S + Ni merged depths
+    const int64_t wave0 = blockIdx.x * (int64_t)(blockDim.x >> 6) + wave;
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int topS1 = top_pow2(S + 1), topS = top_pow2(S), topN = top_pow2(Ni);
     const float ustep = Ni > 1 ? 1.0f / (float)(Ni - 1) : 0.0f;
-    for (int j = 0; j < Ni; ++j) {
-        float u;
-        if (u_in) u = u_in[r * Ni + j];
-        else u = Ni == 1 ? 0.0f : ((j < Ni / 2) ? __fmul_rn(ustep, (float)j) : __fsub_rn(1.0f, __fmul_rn(ustep, (float)(Ni - 1 - j))));
-        // searchsorted(cdf, u, right=True): first index with cdf[idx] > u                  (:120)
-        int lo = 0, hi = S + 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
+    for (int64_t r = wave0; r < n_rays; r += n_waves) {
+        const float* zr = z + r * S;
+        const float* wr = w + r * S;
+        // sum(weights + 1e-5) (:104,:107); the shifted weights are parked in the cdf row
+        float part = 0.0f;
+        for (int s = lane; s < S; s += 64) {
+            const float v = __fadd_rn(wr[s], 1e-5f);
+            cdf[s + 1] = v;
+            zl[s] = zr[s];
+            part = __fadd_rn(part, v);
         }
-        const int below = lo - 1 > 0 ? lo - 1 : 0;
-        const int above = lo < S ? lo : S;
-        // bin edges [z0, mids.., z_{S-1}]: the stratification intervals of ray_utils.py:73-75
-        auto edge = [&](int k) -> float {
-            if (k == 0) return zr[0];
-            if (k == S) return zr[S - 1];
-            return __fmul_rn(0.5f, __fadd_rn(zr[k], zr[k - 1]));
-        };
-        float denom = __fsub_rn(cdf[above], cdf[below]);
-        if (denom < 1e-5f) denom = 1.0f;                                                 // (:131)
-        const float t = __fsub_rn(u, cdf[below]) / denom;
-        const float eb = edge(below), ea = edge(above);
-        const float smpv = __fadd_rn(eb, __fmul_rn(t, __fsub_rn(ea, eb)));               // (:133)
-        smp[j] = smpv;
-        if (samples) samples[r * Ni + j] = smpv;
-    }
-    if (!z_union) return;
-    // sort the new samples (insertion sort in LDS), then merge with the (already sorted) coarse depths  (:136)
-    for (int j = 1; j < Ni; ++j) {
-        const float v = smp[j];
-        int k = j - 1;
-        while (k >= 0 && smp[k] > v) { smp[k + 1] = smp[k]; --k; }
-        smp[k + 1] = v;
-    }
-    float* out = z_union + r * (S + Ni);
-    int a = 0, b = 0;
-    for (int k = 0; k < S + Ni; ++k) {
-        const bool take_z = b >= Ni || (a < S && zr[a] <= smp[b]);
-        out[k] = take_z ? zr[a++] : smp[b++];
+        const float total = wave_sum(part);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // cdf = [0, cumsum(pdf)] (:108-109): prefix sums of 64-sample segments, carried from segment to segment
+        float carry = 0.0f;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const float pdf = s < S ? cdf[s + 1] / total : 0.0f;
+            const float incl = __fadd_rn(carry, wave_incl_sum(pdf, lane));
+            if (s < S) cdf[s + 1] = incl;
+            carry = __shfl(incl, 63, 64);
+        }
+        if (lane == 0) cdf[0] = 0.0f;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // inverse cdf (:112-133)
+        for (int j = lane; j < Ni; j += 64) {
+            float u;
+            if (u_in) u = u_in[r * Ni + j];
+            else u = Ni == 1 ? 0.0f : ((j < Ni / 2) ? __fmul_rn(ustep, (float)j) : __fsub_rn(1.0f, __fmul_rn(ustep, (float)(Ni - 1 - j))));
+            const int idx = count_le(cdf, S + 1, topS1, u);          // searchsorted(cdf, u, right=True)  (:120)
+            const int below = idx - 1 > 0 ? idx - 1 : 0;
+            const int above = idx < S ? idx : S;
+            // bin edges [z0, mids.., z_{S-1}]: the stratification intervals of ray_utils.py:73-75
+            auto edge = [&](int k) -> float {
+                if (k == 0) return zl[0];
+                if (k == S) return zl[S - 1];
+                return __fmul_rn(0.5f, __fadd_rn(zl[k], zl[k - 1]));
+            };
+            float denom = __fsub_rn(cdf[above], cdf[below]);
+            if (denom < 1e-5f) denom = 1.0f;                                                 // (:131)
+            const float t = __fsub_rn(u, cdf[below]) / denom;
+            const float eb = edge(below), ea = edge(above);
+            const float v = __fadd_rn(eb, __fmul_rn(t, __fsub_rn(ea, eb)));                  // (:133)
+            smp[j] = v;
+            if (samples) samples[r * Ni + j] = v;
+        }
+        if (!z_union) continue;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // sorted union (:136): rank the new samples among themselves (stable), then merge ranks by binary search -- a coarse
+        // depth goes in front of an equal new sample
+        for (int j = lane; j < Ni; j += 64) {
+            const float v = smp[j];
+            int rank = 0;
+            for (int i = 0; i < Ni; ++i) {
+                const float o = smp[i];                                                      // same address in every lane: broadcast
+                rank += (o < v || (o == v && i < j)) ? 1 : 0;
+            }
+            ssort[rank] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        for (int k = lane; k < Ni; k += 64) {
+            const float v = ssort[k];
+            uni[k + count_le(zl, S, topS, v)] = v;
+        }
+        for (int a = lane; a < S; a += 64) {
+            const float v = zl[a];
+            uni[a + count_lt(ssort, Ni, topN, v)] = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        float* out = z_union + r * (S + Ni);
+        for (int k = lane; k < S + Ni; k += 64) out[k] = uni[k];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
 }
 
@@ -363,10 +419,10 @@ int launch_sample(const float* rays_o, const float* rays_d, int64_t n_rays, floa
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 
-int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, float* out, hipStream_t s) {
+int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, const float* freq_bands, float* out, hipStream_t s) {
     if (n <= 0) return NRF_OK;
     const int64_t total = n * dim * (2 * L + (include_input ? 1 : 0));
-    hipLaunchKernelGGL(encode_kernel, dim3(grid_for(total, kBlock, 8192)), dim3(kBlock), 0, s, x, n, dim, L, include_input, out);
+    hipLaunchKernelGGL(encode_kernel, dim3(grid_for(total, kBlock, 8192)), dim3(kBlock), 0, s, x, n, dim, L, include_input, freq_bands, out);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 
@@ -419,12 +475,14 @@ int launch_mse_grad(const float* pred, const float* target, int64_t n, float wei
 int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, float* samples, float* z_union,
                       hipStream_t s) {
     if (n_rays <= 0) return NRF_OK;
-    const int row_bytes = (S + 1 + Ni) * 4;
-    int block = 64;
-    while (block > 1 && block * row_bytes > 60 * 1024) block >>= 1;
-    if (block * row_bytes > 60 * 1024) return NRF_EINVAL;
-    const unsigned grid = (unsigned)((n_rays + block - 1) / block);
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3(grid), dim3(block), (size_t)block * row_bytes, s, z, w, n_rays, S, Ni, u, samples, z_union);
+    const int row_bytes = (3 * S + 3 * Ni + 1) * 4;          // one wave's LDS rows (cdf, depths, samples, sorted samples, union)
+    int waves = 4;
+    while (waves > 1 && waves * row_bytes > 60 * 1024) waves >>= 1;
+    if (waves * row_bytes > 60 * 1024) return NRF_EINVAL;
+    int64_t blocks = (n_rays + waves - 1) / waves;
+    if (blocks > 256 * 16) blocks = 256 * 16;                // grid-stride over the rays beyond that
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)blocks), dim3(waves * 64), (size_t)waves * row_bytes, s, z, w, n_rays, S, Ni, u, samples,
+                       z_union);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 

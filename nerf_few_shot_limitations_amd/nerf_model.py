@@ -241,7 +241,7 @@ class NeRFMLP(nn.Module):
                 return mlp_v1_train(self, positions)
             return mlp_v2_train(self, positions, directions, dino_features)
         mode = L.MMA_MODES[self.mma_mode]
-        x = L.dev_f32(positions)
+        x = L.dev_f32(positions)            # reached only when no parameter wants a gradient (inference): inputs carry none either
         h = self.handle(x.device)
         with torch.cuda.device(x.device):
             if self.net == L.NRF_NET_V1:

@@ -32,16 +32,21 @@ def get_rays(H, W, focal, c2w):
     return rays_o, rays_d
 
 
-def sample_points_along_rays(rays_o, rays_d, near, far, N_samples, perturb=True, lindisp=False, t_rand=None, seed=0):
+def sample_points_along_rays(rays_o, rays_d, near, far, N_samples, perturb=True, lindisp=False, t_rand=None, seed=None):
     """pts (...,S,3), z_vals (...,S) for rays of shape (N,3) or (H,W,3).
 
     ray_utils.py:39-84 (flat) == ray_sampler.py:32-61 (image).  `perturb=True`
-    draws the stratified jitter from the kernel's counter RNG (seed) unless
-    `t_rand` (same shape as z_vals, U[0,1)) is given.
+    draws the stratified jitter from the kernel's counter RNG unless `t_rand`
+    (same shape as z_vals, U[0,1)) is given.  seed=None (default): a NEW seed per
+    call taken from torch's CPU generator, so that, as with the reference's
+    torch.rand (ray_utils.py:78), consecutive calls jitter differently and a run
+    repeats under torch.manual_seed; an int pins the pattern.
     """
     L.require_gpu()
-    o = L.dev_f32(rays_o)
-    d = L.dev_f32(rays_d, o.device)
+    o = L.dev_f32(L.refuse_grad(rays_o, "sample_points_along_rays(rays_o)"))
+    d = L.dev_f32(L.refuse_grad(rays_d, "sample_points_along_rays(rays_d)"), o.device)
+    if seed is None:
+        seed = L.fresh_seed() if (perturb and t_rand is None) else 0
     lead = tuple(o.shape[:-1])
     if o.shape[-1] != 3 or d.shape != o.shape:
         raise ValueError("rays_o and rays_d must both be (...,3)")

@@ -41,13 +41,15 @@ def _opts(near, far, n_samples, perturb, t_rand, seed, lindisp, ert_eps, white_b
     o.t_rand = t_rand.data_ptr() if t_rand is not None else None
     o.z_ladder = L.z_ladder(near, far, n_samples, lindisp, device).data_ptr()     # cached per (near, far, S, device)
     o.z_in = z_in.data_ptr() if z_in is not None else None
+    if seed is None:                 # a new jitter pattern per call (ray_utils.py:78 draws torch.rand per call); repeats under torch.manual_seed
+        seed = L.fresh_seed() if (o.perturb and t_rand is None) else 0
     o.rng_seed = int(seed)
     o.ert_eps, o.white_bkgd, o.mma_mode = float(ert_eps), int(bool(white_bkgd)), L.MMA_MODES[mma_mode]
     o.dino = C.pointer(dino) if dino is not None else None
     return o
 
 
-def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb=False, t_rand=None, seed=0, lindisp=False,
+def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb=False, t_rand=None, seed=None, lindisp=False,
                 ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, return_weights=True, return_z=False,
                 z_in=None):
     """Render explicit rays (R,3)/(H,W,3) -> {'rgb' (R,3), 'depth' (R,), 'weights' (R,S)[, 'z_vals' (R,S)]}."""
@@ -80,7 +82,7 @@ def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb
     return out
 
 
-def render_camera(model: NeRFMLP, H, W, focal, c2w, near, far, N_samples=64, ray_begin=0, ray_end=None, perturb=False, seed=0,
+def render_camera(model: NeRFMLP, H, W, focal, c2w, near, far, N_samples=64, ray_begin=0, ray_end=None, perturb=False, seed=None,
                   lindisp=False, ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, device=None,
                   out_rgb=None, out_depth=None):
     """Render rays [ray_begin, ray_end) of an HxW pinhole camera with in-kernel ray generation

@@ -202,8 +202,8 @@ class _MLPV2Fn(torch.autograd.Function):
 def mlp_v2_train(module, positions, directions, dino_features=None):
     """(P,3) positions, (P,3) directions [, (P,C) DINO features for the use_dino=True form] -> rgb (P,3), density (P,1),
     differentiable with respect to the parameters (not the inputs: a feature tensor that requires grad is refused)."""
-    pos = L.dev_f32(positions).reshape(-1, 3)
-    dirs = L.dev_f32(directions, pos.device).reshape(-1, 3)
+    pos = L.dev_f32(L.refuse_grad(positions, "NeRFMLP.forward(positions)")).reshape(-1, 3)
+    dirs = L.dev_f32(L.refuse_grad(directions, "NeRFMLP.forward(directions)"), pos.device).reshape(-1, 3)
     dino = None
     if module.net == L.NRF_NET_V3:
         if dino_features is None:
@@ -217,7 +217,7 @@ def mlp_v2_train(module, positions, directions, dino_features=None):
 
 def mlp_v1_train(module, x_enc):
     """(P, 63) encoded points -> (P, 4) = [sigmoid rgb, raw sigma], differentiable with respect to the parameters."""
-    x = L.dev_f32(x_enc)
+    x = L.dev_f32(L.refuse_grad(x_enc, "NeRFMLP.forward(x_encoded)"))
     pe = 3 * (2 * module.pos_freq + 1)
     flat_in = x.reshape(-1, pe)
     out = _MLPV1Fn.apply(module, flat_in, *module.flat_params().params())

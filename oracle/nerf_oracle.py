@@ -144,14 +144,18 @@ def sample_pdf(z_vals, weights, n_importance, u=None):
 # a4  positional encoding
 # --------------------------------------------------------------------------
 
-def positional_encoding(x, num_freqs: int, include_input: bool = True):
+def positional_encoding(x, num_freqs: int, include_input: bool = True, log_sampling: bool = True):
     """[x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)].
 
     src/models/positional_encoding.py:13-14,27-33 == src/models/nerf_mlp.py:13-33.
-    Blocks of D values, sin before cos, frequency-major.
+    Blocks of D values, sin before cos, frequency-major.  log_sampling=False: frequencies
+    linspace(1, 2^(L-1), L) (positional_encoding.py:17-18).
     """
     x = torch.as_tensor(x, dtype=torch.float32)
-    freqs = 2.0 ** torch.linspace(0.0, num_freqs - 1, num_freqs)
+    if log_sampling:
+        freqs = 2.0 ** torch.linspace(0.0, num_freqs - 1, num_freqs)
+    else:
+        freqs = torch.linspace(2.0 ** 0.0, 2.0 ** (num_freqs - 1), num_freqs)
     out = [x] if include_input else []
     for f in freqs:
         out.append(torch.sin(x * f))

@@ -144,6 +144,9 @@ def main():
     enc_b = npf(ref_mlp.PositionalEncoding(10)(x))
     assert np.array_equal(enc_b, enc["enc_L10"])
     save("encoding", x=npf(x), **enc)
+    # log_sampling=False (positional_encoding.py:17-18; no caller of the reference uses it), with and without the raw input
+    save("encoding_linear", x=npf(x), enc_L6=npf(RefPE(6, log_sampling=False)(x)),
+         enc_L10_noinput=npf(RefPE(10, include_input=False, log_sampling=False)(x)))
 
     # ---------------- a5 V1 MLP ----------------------------------------------------
     P = 384

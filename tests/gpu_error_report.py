@@ -56,3 +56,37 @@ for scene in ("fog", "solid"):
         rgb, depth = N.render_camera(m, Hc, Wc, O.focal_for(Wc), c2w, 2.0, 6.0, Sc)
         print(f"100x100x32 v1 {scene} {mode}: rgb {md(rgb, ref['rgb'].numpy()):.2e} depth {md(depth, ref['depth'].numpy()):.2e} "
               f"psnr_vs_oracle {O.psnr(rgb.cpu(), ref['rgb']):.1f} dB")
+
+# ---- numbers behind the 16-bit bounds of tests/test_gpu_parity.py (stable rays = |sigma_last| > 0.5 in the oracle: the
+#      reference's tail rule dists[-1]=1e10 makes alpha_last a step function of sigma_last, nerf_mlp.py:182)
+p = O.make_weights("v1", 0, "solid")
+roo, rdo = O.get_rays(Hc, Wc, O.focal_for(Wc), c2w)
+ref = O.render_rays(p, "v1", roo, rdo, 2.0, 6.0, Sc)
+gt = O.render_rays(p, "v1", roo, rdo, 2.0, 6.0, 2 * Sc)["rgb"]
+sig_last = O.mlp_v1(p, O.positional_encoding(roo.reshape(-1, 3) + rdo.reshape(-1, 3) * 6.0, 10))[:, 3]
+stable = sig_last.abs() > 0.5
+ps_ref = O.psnr(ref["rgb"], gt)
+for mode in ("f16x3", "f16", "bf16"):
+    m, _ = mk("v1", "solid", mode)
+    rgb, depth = N.render_camera(m, Hc, Wc, O.focal_for(Wc), c2w, 2.0, 6.0, Sc)
+    err = (rgb.cpu() - ref["rgb"]).abs().max(-1).values
+    derr = (depth.cpu() - ref["depth"]).abs()
+    print(f"stable-ray bounds 100x100x32 solid {mode}: rgb max {float(err[stable].max()):.3e} median {float(err.median()):.3e} "
+          f"depth max {float(derr[stable].max()):.3e} psnr {O.psnr(rgb.cpu(), ref['rgb']):.2f} dB  psnr-delta vs 2S ground truth {abs(O.psnr(rgb.cpu(), gt) - ps_ref):.5f} dB")
+H8 = W8 = 800
+b0, b1 = 400 * W8, 402 * W8
+ro8, rd8 = O.get_rays(H8, W8, O.focal_for(W8), c2w)
+ref8 = O.render_rays(p, "v1", ro8.reshape(-1, 3)[b0:b1], rd8.reshape(-1, 3)[b0:b1], 2.0, 6.0, 64)
+for mode in ("f16", "bf16"):
+    m, _ = mk("v1", "solid", mode)
+    rgb, _ = N.render_camera(m, H8, W8, O.focal_for(W8), c2w, 2.0, 6.0, 64, ray_begin=b0, ray_end=b1)
+    print(f"800x800x64 band solid {mode}: psnr vs oracle {O.psnr(rgb.cpu(), ref8['rgb']):.2f} dB")
+e = g("end_to_end")
+p3 = O.make_weights("v3", 2, "fog")
+m3 = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode="bf16")
+m3.load_state_dict(p3, strict=False); m3 = m3.cuda().eval()
+fm = torch.from_numpy(O.uniform01(7, 28 * 28 * 64).reshape(1, 28, 28, 64) * 2 - 1)
+dino = dict(features=fm, pose=T(e["c2w"]), focal=float(e["focal"]), H=H, W=W)
+for mode in ("f16", "bf16"):
+    out = N.render_rays(m3, ro, rd, 2.0, 6.0, S, dino=dino, mma_mode=mode)
+    print(f"e2e v3 fog {mode}: rgb {md(out['rgb'], e['v3_fog_plain_rgb']):.2e} depth {md(out['depth'], e['v3_fog_plain_depth']):.2e} psnr {O.psnr(out['rgb'].cpu(), T(e['v3_fog_plain_rgb'])):.1f} dB")

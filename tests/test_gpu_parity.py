@@ -117,6 +117,39 @@ def test_samples_internal_rng_is_stratified(N):
     assert abs(float(u.mean()) - 0.5) < 0.01 and abs(float(u.std()) - 12 ** -0.5) < 0.01
 
 
+def test_jitter_is_fresh_per_call_and_repeats_under_manual_seed(N):
+    """perturb=True without t_rand / seed: like the reference's torch.rand per call (ray_utils.py:78), two consecutive calls
+    draw different stratified offsets, and a run repeats under torch.manual_seed -- through sample_points_along_rays,
+    render_rays and the trainer-shaped NeRFRenderer (train.py:188-196 passes no seed)."""
+    o = torch.zeros(64, 3); d = torch.tensor([[0., 0., -1.]]).expand(64, 3)
+    torch.manual_seed(11)
+    _, z1 = N.sample_points_along_rays(o, d, 2.0, 6.0, 16, perturb=True)
+    _, z2 = N.sample_points_along_rays(o, d, 2.0, 6.0, 16, perturb=True)
+    torch.manual_seed(11)
+    _, z3 = N.sample_points_along_rays(o, d, 2.0, 6.0, 16, perturb=True)
+    assert not torch.equal(z1, z2) and torch.equal(z1, z3)
+    _, za = N.sample_points_along_rays(o, d, 2.0, 6.0, 16, perturb=True, seed=5)
+    _, zb = N.sample_points_along_rays(o, d, 2.0, 6.0, 16, perturb=True, seed=5)
+    _, zc = N.sample_points_along_rays(o, d, 2.0, 6.0, 16, perturb=False)
+    _, zd = N.sample_points_along_rays(o, d, 2.0, 6.0, 16, perturb=False)
+    assert torch.equal(za, zb) and torch.equal(zc, zd)
+    m, _ = model_v2(N, "solid", "bf16")
+    ro, rd = N.get_rays(8, 8, O.focal_for(8), T(O.LEGO_LIKE_C2W))
+    torch.manual_seed(3)
+    a = N.render_rays(m, ro, rd, 2.0, 6.0, 16, perturb=True, return_z=True)
+    b = N.render_rays(m, ro, rd, 2.0, 6.0, 16, perturb=True, return_z=True)
+    torch.manual_seed(3)
+    c = N.render_rays(m, ro, rd, 2.0, 6.0, 16, perturb=True, return_z=True)
+    assert not torch.equal(a["z_vals"], b["z_vals"]) and torch.equal(a["z_vals"], c["z_vals"]) and torch.equal(a["rgb"], c["rgb"])
+    r = N.NeRFRenderer(m.train(), 2.0, 6.0)
+    x = r.render_rays(ro.view(-1, 3), rd.view(-1, 3), 0, 16)
+    y = r.render_rays(ro.view(-1, 3), rd.view(-1, 3), 0, 16)
+    assert not torch.equal(x["rgb"], y["rgb"])
+    m.eval()
+    with pytest.raises(NotImplementedError):            # rays that require grad are refused under grad mode, not detached
+        N.sample_points_along_rays(o.clone().requires_grad_(True), d, 2.0, 6.0, 16)
+
+
 # ------------------------------------------------------------------ a4 encoding
 def test_encoding_golden(N, golden):
     g = golden("encoding")
@@ -127,6 +160,14 @@ def test_encoding_golden(N, golden):
         assert maxdiff(e, g[f"enc_L{L}"]) <= 1e-6
     k = golden("kat")
     assert maxdiff(N.PositionalEncoding(2)(torch.tensor([.5, -1., 2.])), k["k3_enc"]) <= 2e-7
+    # log_sampling=False (positional_encoding.py:17-18): linearly spaced frequencies, arguments up to 6 * 512
+    gl = golden("encoding_linear")
+    assert maxdiff(N.PositionalEncoding(6, log_sampling=False)(T(gl["x"])), gl["enc_L6"]) <= 1e-6
+    pe = N.PositionalEncoding(10, include_input=False, log_sampling=False)
+    e = pe(T(gl["x"]))
+    assert e.shape[1] == pe.get_output_dim(3) == 60 and maxdiff(e, gl["enc_L10_noinput"]) <= 1e-6
+    with pytest.raises(NotImplementedError):            # no gradient with respect to the coordinates: refused, not detached
+        N.PositionalEncoding(4)(torch.zeros(2, 3, requires_grad=True))
 
 
 # ------------------------------------------------------------------ a9/a10 compositor

@@ -105,6 +105,9 @@ def test_encoding_golden(golden):
         e = O.positional_encoding(T(g["x"]), L)
         assert e.shape[1] == O.encoded_dim(L)
         close(e, g[f"enc_L{L}"])
+    g = golden("encoding_linear")                      # log_sampling=False (positional_encoding.py:17-18)
+    close(O.positional_encoding(T(g["x"]), 6, log_sampling=False), g["enc_L6"])
+    close(O.positional_encoding(T(g["x"]), 10, include_input=False, log_sampling=False), g["enc_L10_noinput"])
 
 
 @pytest.mark.parametrize("scene", ["fog", "solid"])

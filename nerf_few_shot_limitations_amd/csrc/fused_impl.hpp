@@ -1,12 +1,10 @@
 // fused_impl.hpp -- the fused sample -> encode -> MLP -> composite renderer and the staged MLP
 // forward, hand-written for gfx950 (CDNA4).  See mlp_core.hpp for the MFMA / weight-stream design.
 //
-// Work mapping of the renderer: a persistent workgroup (4 waves, one per SIMD, 1 workgroup per CU
-// because of its 145 KiB of LDS) walks ray tiles of 4*32*NT rays.  Inside a wave LANE <-> RAY: the
-// wave marches its 32*NT rays front to back, one sample per ray per MLP pass, so a ray's
-// transmittance / colour / depth accumulators live in the registers of the lane that owns it
-// (lane (c,h) owns ray 32h+c of the wave) and a whole workgroup stops marching a tile as soon as
-// every one of its rays has T < ert_eps.
+// Work mapping of the renderer: a persistent workgroup (8 waves, two per SIMD -- 4 in the fp32 / split-f16 modes --, 1 workgroup
+// per CU because of its ~147 KiB of LDS) walks ray tiles.  Inside a wave LANE <-> RAY: the wave marches its rays front to back,
+// so a ray's transmittance / colour / depth accumulators belong to ONE lane (parked in LDS between passes) and compositing
+// never crosses lanes.  Early ray termination (ert_eps > 0) runs on render_queue_kernel: lanes refill from a ray queue.
 #pragma once
 #include <atomic>
 #include <cstdlib>
@@ -78,22 +76,36 @@ __device__ __forceinline__ int64_t global_ray(const RenderArgs& a, int64_t i, in
 // ---------------------------------------------------------------------------------------------
 // fused renderer
 // ---------------------------------------------------------------------------------------------
-// ERT: built with the early-ray-termination machinery (selected when ert_eps > 0); the plain build carries none of it
-template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
+// Per-lane ray state (origin, direction, |d|, next depth, the compositor's six accumulators) is parked in LDS
+// ([field][thread]: lane-linear, conflict-free) and pulled into registers only around the few instructions that use it:
+// nothing per-ray is live across the MLP, whose register budget is full -- a compiler spill to scratch there is a VMEM
+// op whose wait drains the LDS-DMA weight queue (the round-1 V2 / V3 builds carried ~80 spilled dwords).
+enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_NORM, F_Z, F_T, F_R, F_G, F_B, F_DEPTH, F_ACC, kFields };
+constexpr int kLadderLds = 1024;      // depth-ladder entries cached in LDS by the ray-queue kernel (per-lane sample indices gather from it)
+constexpr int kLdsState = kLdsRing + kBiasMaxFloats * 4 + 64 + kLadderLds * 4;     // byte offset of the state rows
+
+template <class Net, class Mode, int WAVES, int LP, int LD>
 __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P) {
+    constexpr int NT = 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NRF_LDS char* lds = (NRF_LDS char*)smem;
     NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
-    NRF_LDS int* flags = (NRF_LDS int*)(bias + kBiasMaxFloats);
+    NRF_LDS float* st = (NRF_LDS float*)(lds + kLdsState);
+    constexpr int nthreads = WAVES * 64;
+    // ONE address register for this thread's column; fields sit at immediate offsets f*nthreads*4 (< 64 KiB, the DS offset
+    // field).  Everything derived from the thread id is re-derived inside each pass from an opaque copy (tid_now): loop-invariant
+    // per-lane values would otherwise be hoisted, spilled at the MLP's register peak and reloaded from scratch every pass.
+    int tid_now = threadIdx.x;
+    NRF_LDS float* st_me = st + tid_now;
+    auto ST = [&](int f) -> NRF_LDS float& { return st_me[f * nthreads]; };
     typedef typename Mode::Act Act;
     constexpr int KT0 = pe_tiles(LP);
-    constexpr int TILE = WAVES * 32 * NT;
 
-    const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
+    int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
 
-    Pipe<WAVES, ERT> pipe;
+    Pipe<WAVES> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 #ifdef NRF_YOUNG_PRIO
@@ -103,112 +115,107 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     const RenderArgs& a = P.a;
     const int S = a.n_samples;
     const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, a.z_ladder);
-    const int own = (NT == 2) ? h : 0;
-    const bool owner = h < NT;
     // Samples per ray and MLP pass (host: pick_spw_log2).  The wave's 32 sample columns are RPW = 32/SPW rays x SPW consecutive
     // samples: column c = ray (c mod RPW), sample (pass*SPW + c div RPW).  A ray is still composited front to back by ONE lane
-    // (column c < RPW), which fetches the other columns' network outputs with ds_bpermute -- the per-ray sequence of operations,
-    // hence every bit of the result, does not depend on SPW.  What SPW buys: frames whose ray count does not fill whole rounds
-    // of 256-ray tiles over the CUs (400x400; an 80 000-ray shard) are cut into 2x / 4x as many, shorter, work items.
-    const int spw_log2 = (NT == 1 && !ERT) ? a.spw_log2 : 0;
+    // (column c < RPW of the low lane half), which fetches the other columns' network outputs with ds_bpermute -- the per-ray
+    // sequence of operations, hence every bit of the result, does not depend on SPW.  What SPW buys: frames whose ray count
+    // does not fill whole rounds of 256-ray tiles over the CUs (400x400; an 80 000-ray shard) are cut into 2x / 4x as many,
+    // shorter, work items.
+    const int spw_log2 = a.spw_log2;
     const int SPW = 1 << spw_log2, RPW = 32 >> spw_log2;
-    const int cr = c & (RPW - 1), cj = c >> (5 - spw_log2);
-    const int64_t tile_rays = (int64_t)WAVES * NT * RPW;
+    const int64_t tile_rays = (int64_t)WAVES * RPW;
     const int n_pass = (S + SPW - 1) >> spw_log2;
 
+    auto z_ray = [&](int64_t ray, int s) -> float {
+        if (a.z_in) return a.z_in[ray * S + s];
+        if (!a.perturb) return ladder_z(lad, s);
+        float u;
+        if (a.t_rand) {
+            u = a.t_rand[ray * S + s];
+        } else {
+            int ci;
+            const int64_t g = global_ray(a, ray, ci);
+            u = counter_uniform(a.seed + (uint64_t)ci * 0x51ED27ull, (uint64_t)g, (uint32_t)s);
+        }
+        return ladder_z_jitter(lad, s, u);
+    };
+
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
-        int64_t rid[NT];
-        float o[NT][3], d[NT][3];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int64_t r = tile * tile_rays + wave * (RPW * NT) + RPW * n + cr;
-            rid[n] = r < a.n_rays ? r : a.n_rays - 1;
+        // this column's ray (clamped: the columns past the last ray of a ragged tile repeat it and store nothing)
+        auto column_ray = [&]() -> int64_t {
+            const int64_t r = tile * tile_rays + wave * RPW + (c & (RPW - 1));
+            return r < a.n_rays ? r : a.n_rays - 1;
+        };
+        {
+            const int64_t rid = column_ray();
+            float o[3], d[3];
             if (a.camera_mode) {
                 int ci;
-                const int64_t g = global_ray(a, rid[n], ci);
-                camera_ray(a.cams[ci], g, o[n], d[n]);
+                const int64_t g = global_ray(a, rid, ci);
+                camera_ray(a.cams[ci], g, o, d);
             } else {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { o[n][k] = a.rays_o[rid[n] * 3 + k]; d[n][k] = a.rays_d[rid[n] * 3 + k]; }
+                for (int k = 0; k < 3; ++k) { o[k] = a.rays_o[rid * 3 + k]; d[k] = a.rays_d[rid * 3 + k]; }
             }
+            ST(F_OX) = o[0]; ST(F_OY) = o[1]; ST(F_OZ) = o[2];
+            ST(F_DX) = d[0]; ST(F_DY) = d[1]; ST(F_DZ) = d[2];
+            ST(F_NORM) = ray_norm(d);
+            ST(F_Z) = z_ray(rid, 0);                 // depth of the ray's next sample to composite
+            ST(F_T) = 1.0f; ST(F_R) = 0.0f; ST(F_G) = 0.0f; ST(F_B) = 0.0f; ST(F_DEPTH) = 0.0f; ST(F_ACC) = 0.0f;
         }
-        const int64_t own_rid = (own == 0) ? rid[0] : rid[NT - 1];
-        const int64_t own_raw = tile * tile_rays + wave * (RPW * NT) + RPW * own + cr;
-        const bool own_valid = owner && cj == 0 && own_raw < a.n_rays;
-        float own_d[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) own_d[k] = (own == 0) ? d[0][k] : d[NT - 1][k];
-        const float norm = ray_norm(own_d);
-
-        // view direction = raw rays_d (train.py:225); encoded on demand inside the network walk
-        auto dirT = [&](Act (&dt)[1][NT]) {
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                Act t1[pe_tiles(LD)];
-                encode3<Mode, LD>(d[n], h, t1);
-                dt[0][n] = t1[0];
-            }
-        };
-
-        auto z_ray = [&](int64_t ray, int s) -> float {
-            if (a.z_in) return a.z_in[ray * S + s];
-            if (!a.perturb) return ladder_z(lad, s);
-            float u;
-            if (a.t_rand) {
-                u = a.t_rand[ray * S + s];
-            } else {
-                int ci;
-                const int64_t g = global_ray(a, ray, ci);
-                u = counter_uniform(a.seed + (uint64_t)ci * 0x51ED27ull, (uint64_t)g, (uint32_t)s);
-            }
-            return ladder_z_jitter(lad, s, u);
-        };
-
-        Composite comp;
-        comp.reset();
-        pipe.skip = 0;
-        float zo = z_ray(own_rid, 0);            // depth of the own ray's next sample to composite
-        int done = 0;                            // samples composited so far
 
         for (int p = 0; p < n_pass; ++p) {
-            // depth of this column's sample (columns past the last sample repeat it; their outputs are not used)
-            float zc[NT];
-            {
-                const int sc = p * SPW + cj;
-                const int se = sc < S ? sc : S - 1;
-#pragma unroll
-                for (int n = 0; n < NT; ++n) zc[n] = (SPW == 1 && n == own) ? zo : z_ray(rid[n], se);
-            }
+            tid_now = threadIdx.x;
+            asm volatile("" : "+v"(tid_now));
+            lane = tid_now & 63; c = lane & 31; h = lane >> 5;
+            st_me = st + tid_now;
 
+            // view direction = raw rays_d (train.py:225); encoded on demand inside the network walk
+            auto dirT = [&](Act (&dt)[1][NT]) {
+                const float d[3] = {ST(F_DX), ST(F_DY), ST(F_DZ)};
+                Act t1[pe_tiles(LD)];
+                encode3<Mode, LD>(d, h, t1);
+                dt[0][0] = t1[0];
+            };
             // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
             auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
-                if constexpr (ERT) if (pipe.skip) return;     // terminated wave: its layers are skipped too, nothing reads x
+                // depth of this column's sample (columns past the last sample repeat it; their outputs are not used)
+                float zc;
+                if (SPW == 1) {
+                    zc = ST(F_Z);
+                } else {
+                    const int sc = p * SPW + (c >> (5 - spw_log2));
+                    zc = z_ray(column_ray(), sc < S ? sc : S - 1);
+                }
+                float pt[3];
+                pt[0] = point_on_ray(ST(F_OX), ST(F_DX), zc);
+                pt[1] = point_on_ray(ST(F_OY), ST(F_DY), zc);
+                pt[2] = point_on_ray(ST(F_OZ), ST(F_DZ), zc);
+                Act e1[KT0];
+                encode3<Mode, LP>(pt, h, e1, w0[0]);
 #pragma unroll
-                for (int n = 0; n < NT; ++n) {
-                    float pt[3];
+                for (int t = 0; t < KT0; ++t) x[t][0] = e1[t];
+                if constexpr (Net::kDino) {
+                    constexpr int DT = Net::KT0 - KT0;
+                    const DinoTaps tp = dino_taps(a.dino, pt);
+                    Act dt[DT];
+                    dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[0], dt);
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) pt[k] = point_on_ray(o[n][k], d[n][k], zc[n]);
-                    Act e1[KT0];
-                    encode3<Mode, LP>(pt, h, e1, w0[n]);
-#pragma unroll
-                    for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
-                    if constexpr (Net::kDino) {
-                        constexpr int DT = Net::KT0 - KT0;
-                        const DinoTaps tp = dino_taps(a.dino, pt);
-                        Act dt[DT];
-                        dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
-#pragma unroll
-                        for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
-                    }
+                    for (int t = 0; t < DT; ++t) x[KT0 + t][0] = dt[t];
                 }
             };
 
             float out4[NT][4];
             Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
 
-            float v0[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v0[k] = (own == 0) ? out4[0][k] : out4[NT - 1][k];
+            // ---- composite this pass's SPW samples of the lane's ray, front to back --------------------------------------
+            const int64_t rid = column_ray();
+            const int64_t raw = tile * tile_rays + wave * RPW + (c & (RPW - 1));
+            const bool own_valid = h == 0 && c < RPW && raw < a.n_rays;
+            Composite comp;
+            comp.T = ST(F_T); comp.r = ST(F_R); comp.g = ST(F_G); comp.b = ST(F_B); comp.depth = ST(F_DEPTH); comp.acc = ST(F_ACC);
+            float zo = ST(F_Z);
+            const float norm = ST(F_NORM);
             for (int j = 0; j < SPW; ++j) {
                 const int s = p * SPW + j;
                 if (s >= S) break;
@@ -216,63 +223,44 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                 float v[4];
                 if (j == 0) {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = v0[k];
+                    for (int k = 0; k < 4; ++k) v[k] = out4[0][k];
                 } else {
                     // the outputs of sample s of this lane's ray sit in column c + j*RPW of the same lane half
                     const int src = (lane + j * RPW) << 2;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, v0[k])));
+                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, out4[0][k])));
                 }
-                const float zn = last ? 0.0f : z_ray(own_rid, s + 1);
+                const float zn = last ? 0.0f : z_ray(rid, s + 1);
                 const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zo), norm);
-                float w = 0.0f;
-                if (!ERT || !pipe.skip)      // a terminated wave's MLP outputs are stale registers: they must not reach the accumulators
-                    w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
-                                                          sigmoid_sel<Mode::FAST_EXP>(v[2]), zo, dist);
+                const float w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
+                                                                  sigmoid_sel<Mode::FAST_EXP>(v[2]), zo, dist);
                 if (own_valid) {
-                    if (a.weights) a.weights[own_rid * S + s] = w;
-                    if (a.z_vals) a.z_vals[own_rid * S + s] = zo;
+                    if (a.weights) a.weights[rid * S + s] = w;
+                    if (a.z_vals) a.z_vals[rid * S + s] = zo;
                 }
                 zo = zn;
-                done = s + 1;
             }
-
-            if (ERT && a.ert_eps > 0.0f && done < S) {
-                // early termination (SPW = 1 here: p is the sample index): a wave whose rays are all opaque stops computing
-                // (pipe.skip), the workgroup leaves the sample loop once all of its waves have
-                const int wave_dead = __all((!own_valid) || (comp.T < a.ert_eps));
-                pipe.skip = (uint32_t)__builtin_amdgcn_readfirstlane(wave_dead ? 1 : 0);   // provably wave-uniform: scalar branch
-                if ((p & 3) == 3) {       // the workgroup-wide vote (LDS flag + barrier) only every fourth step
-                    if (lane == 0) flags[((p >> 2) & 1) * WAVES + wave] = wave_dead;
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                    const NRF_LDS int* fl = flags + ((p >> 2) & 1) * WAVES;
-                    int all_dead = 1;
-#pragma unroll
-                    for (int wv = 0; wv < WAVES; ++wv) all_dead &= fl[wv];
-                    if (all_dead) break;
-                }
-            }
+            ST(F_T) = comp.T; ST(F_R) = comp.r; ST(F_G) = comp.g; ST(F_B) = comp.b; ST(F_DEPTH) = comp.depth; ST(F_ACC) = comp.acc;
+            ST(F_Z) = zo;
         }
-        if (own_valid) {
-            // samples skipped by early termination carry weight < ert_eps: report 0 and their depths
-            for (int s2 = done; s2 < S; ++s2) {
-                if (a.weights) a.weights[own_rid * S + s2] = 0.0f;
-                if (a.z_vals) a.z_vals[own_rid * S + s2] = z_ray(own_rid, s2);
-            }
-            float r = comp.r, g = comp.g, b = comp.b;
-            if (a.white_bkgd) {                                      // nerf_mlp.py:209-212
-                const float bg = __fsub_rn(1.0f, comp.acc);
-                r = __fadd_rn(r, bg); g = __fadd_rn(g, bg); b = __fadd_rn(b, bg);
-            }
-            if (a.interleaved) {
-                *(float4*)(a.rgb + own_rid * 4) = make_float4(r, g, b, comp.depth);     // (R,4) rows [r,g,b,depth]: the gather buffer
-            } else {
-                a.rgb[own_rid * 3 + 0] = r;
-                a.rgb[own_rid * 3 + 1] = g;
-                a.rgb[own_rid * 3 + 2] = b;
-                a.depth[own_rid] = comp.depth;
+
+        {
+            const int64_t raw = tile * tile_rays + wave * RPW + (c & (RPW - 1));
+            if (h == 0 && c < RPW && raw < a.n_rays) {
+                float r = ST(F_R), g = ST(F_G), b = ST(F_B);
+                if (a.white_bkgd) {                                      // nerf_mlp.py:209-212
+                    const float bg = __fsub_rn(1.0f, ST(F_ACC));
+                    r = __fadd_rn(r, bg); g = __fadd_rn(g, bg); b = __fadd_rn(b, bg);
+                }
+                if (a.interleaved) {
+                    *(float4*)(a.rgb + raw * 4) = make_float4(r, g, b, ST(F_DEPTH));     // (R,4) rows [r,g,b,depth]: the gather buffer
+                } else {
+                    a.rgb[raw * 3 + 0] = r;
+                    a.rgb[raw * 3 + 1] = g;
+                    a.rgb[raw * 3 + 2] = b;
+                    a.depth[raw] = ST(F_DEPTH);
+                }
             }
         }
     }
@@ -290,7 +278,6 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 // agree on termination without exchanging anything; only the low lane stores.  Per-ray arithmetic is exactly that of
 // render_kernel, so with ert_eps -> 0 the image is the same; with ert_eps > 0 each ray stops at ITS OWN T < eps.
 constexpr int kStrip = 32;        // rays handed out per atomic: one wave-load, so that the frame's last strips spread over all waves (128 left a 4-batch tail: +18 %)
-constexpr int kLadderLds = 1024;      // depth-ladder entries cached in LDS (per-lane sample indices gather from it)
 
 template <class Net, class Mode, int WAVES, int LP, int LD>
 __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKArgs P) {
@@ -303,8 +290,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     // Per-lane ray state lives in LDS ([field][thread]: lane-linear, conflict-free) and is only pulled into registers
     // around the few instructions that use it: nothing per-ray is live across the MLP, whose register budget is full
     // (a compiler spill to scratch there is a VMEM op whose wait drains the LDS-DMA weight queue).
-    NRF_LDS float* st = zl + kLadderLds;
-    enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_NORM, F_Z, F_T, F_R, F_G, F_B, F_DEPTH, F_ACC, kFields };
+    NRF_LDS float* st = zl + kLadderLds;                  // == lds + kLdsState
     constexpr int nthreads = WAVES * 64;
     // ONE address register for this thread's column; fields sit at immediate offsets f*nthreads*4 (< 64 KiB, the DS
     // offset field).  The empty asm keeps the compiler from folding the (> 64 KiB) region base into 14 separate
@@ -321,8 +307,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const RenderArgs& a = P.a;
     const int S = a.n_samples;
-    const bool table = a.z_ladder != nullptr;             // host guarantees S <= kLadderLds then
-    if (table)
+    const bool table = a.z_ladder != nullptr;             // a caller-computed ladder: cached in LDS when it fits
+    const bool cached = table && S <= kLadderLds;
+    if (cached)
         for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder[i];
     ST(F_OX) = 0.f; ST(F_OY) = 0.f; ST(F_OZ) = 0.f; ST(F_DX) = 0.f; ST(F_DY) = 0.f; ST(F_DZ) = -1.f; ST(F_Z) = 1.f;
     load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
@@ -332,7 +319,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     pipe.start();
 
     const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, nullptr);
-    auto z_base = [&](int s) -> float { return table ? zl[s] : ladder_z(lad, s); };
+    auto z_base = [&](int s) -> float { return cached ? zl[s] : (table ? a.z_ladder[s] : ladder_z(lad, s)); };
     auto z_of = [&](int64_t ray, int s) -> float {
         if (a.z_in) return a.z_in[ray * S + s];
         if (!a.perturb) return z_base(s);
@@ -645,20 +632,20 @@ inline int pick_spw_log2(int64_t n_rays, int S, int waves, int cu) {
     return best;
 }
 
-template <class Net, class Mode, int NT, int WAVES, int LP, int LD, bool ERT>
+template <class Net, class Mode, int WAVES, int LP, int LD>
 int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
-    auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD, ERT>;
+    auto kernel = render_kernel<Net, Mode, WAVES, LP, LD>;
     static unsigned char done[64] = {};
-    const int prepared = prepare(kernel, net.device, done, err);
+    const int prepared = prepare(kernel, net.device, done, err, kLdsBytesQueue);
     if (prepared != NRF_OK) return prepared;
     RenderKArgs k;
     k.net = net_args(net, mode);
     k.a = a;
-    k.a.spw_log2 = (NT == 1 && !ERT) ? pick_spw_log2(a.n_rays, a.n_samples, WAVES, net.cu_count) : 0;
-    const int64_t tile = (int64_t)WAVES * NT * (32 >> k.a.spw_log2);
+    k.a.spw_log2 = pick_spw_log2(a.n_rays, a.n_samples, WAVES, net.cu_count);
+    const int64_t tile = (int64_t)WAVES * (32 >> k.a.spw_log2);
     k.n_tiles = (a.n_rays + tile - 1) / tile;
     const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytes, s, k);
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytesQueue, s, k);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("render launch: ") + hipGetErrorString(e); return NRF_EHIP; }
     return NRF_OK;
@@ -689,17 +676,13 @@ int run_render_queue(const DeviceNet& net, int mode, RenderArgs a, hipStream_t s
 
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
+    static_assert(NT == 1, "the renderers march one sample tile per wave");
     if (a.ert_eps > 0.0f) {
-        // per-ray early termination on the ray-queue kernel (one ray per lane pair); the tile-synchronous ERT build
-        // remains for the 4x2 geometry and for depth ladders too long for the LDS cache
-        static const bool tile_ert = [] { const char* e = getenv("NRF_ERT"); return e && std::string(e) == "tile"; }();
-        if constexpr (NT == 1) {
-            if (!tile_ert && net.queues && a.n_rays < (int64_t)1 << 31 && (!a.z_ladder || a.n_samples <= kLadderLds))
-                return run_render_queue<Net, Mode, WAVES, LP, LD>(net, mode, a, s, err);
-        }
-        return run_render_v<Net, Mode, NT, WAVES, LP, LD, true>(net, mode, a, s, err);
+        // per-ray early termination: the ray-queue kernel (one ray per lane pair, refilled from a device-wide queue)
+        if (!net.queues || a.n_rays >= (int64_t)1 << 31) { err = "early ray termination: launch too large (>= 2^31 rays)"; return NRF_EINVAL; }
+        return run_render_queue<Net, Mode, WAVES, LP, LD>(net, mode, a, s, err);
     }
-    return run_render_v<Net, Mode, NT, WAVES, LP, LD, false>(net, mode, a, s, err);
+    return run_render_v<Net, Mode, WAVES, LP, LD>(net, mode, a, s, err);
 }
 
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
@@ -727,22 +710,13 @@ bool check_net(const DeviceNet& net, int mode, std::string& err) {
 
 }  // namespace
 
-// Workgroup geometry per arithmetic mode: 16-bit modes run 8 waves x 32 samples (two waves per SIMD, <= 256
-// registers, each covering the other's epilogue / waits); NRF_GEOMETRY=4x2 selects 4 waves x 64 samples (V1 only).
-// The fp32 mode keeps 4 waves x 32 samples (its fp32 activations need > 256 registers).
-static bool wide_waves() {
-    static const bool w = [] { const char* e = getenv("NRF_GEOMETRY"); return !(e && std::string(e) == "4x2"); }();
-    return w;
-}
-
+// Workgroup geometry per arithmetic mode: the 16-bit modes run 8 waves x 32 samples (two waves per SIMD, <= 256 registers, each
+// covering the other's epilogue / waits); the fp32 and split-f16 modes 4 waves x 32 samples (their activations take 16 registers
+// per tile: one wave per SIMD with the whole 512-register file).
 #define NRF_DISPATCH_MODE(FN, NET, LP, ...)                                                                 \
     switch (mode) {                                                                                         \
-        case NRF_MMA_BF16:                                                                                  \
-            if (wide_waves()) return FN<NET<ModeBF16, 1, LP>, ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);         \
-            return FN<NET<ModeBF16, 2, LP>, ModeBF16, 2, 4, LP, 4>(__VA_ARGS__);                            \
-        case NRF_MMA_F16:                                                                                   \
-            if (wide_waves()) return FN<NET<ModeF16, 1, LP>, ModeF16, 1, 8, LP, 4>(__VA_ARGS__);           \
-            return FN<NET<ModeF16, 2, LP>, ModeF16, 2, 4, LP, 4>(__VA_ARGS__);                              \
+        case NRF_MMA_BF16: return FN<NET<ModeBF16, 1, LP>, ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);             \
+        case NRF_MMA_F16:  return FN<NET<ModeF16, 1, LP>, ModeF16, 1, 8, LP, 4>(__VA_ARGS__);               \
         case NRF_MMA_F16X3: return FN<NET<ModeF16X3, 1, LP>, ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);         \
         default: return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                         \
     }

@@ -4,8 +4,10 @@
 What `NeRFDINOTrainer.evaluate` does (src/training/train.py:294-342) for a use_dino=False config, on the fused renderer:
 load the YAML unchanged, the Blender split, the checkpoint (either key set), render every view (8 per launch), score
 PSNR/SSIM, dump PNGs and a metrics.json.  Without --checkpoint the weights are the module's random init (smoke use).
-use_dino configs need the DINOv2 feature map of the source view, which cannot be produced offline: pass --dino-map with a
-saved (1,Hp,Wp,C) tensor, otherwise the CLI refuses.
+use_dino configs condition every test view on the feature map and pose of TRAINING view 0 (train.py:203-208: `feat_idx = 0` outside
+training).  The map comes from the config's extractor (config.dino_model_from_config) run once on that view -- --dino-weights
+names a local transformers Dinov2Model checkpoint, --dino-random-init builds it with random weights (the published weights are
+not available offline) -- or from --dino-map, a saved (1,Hp,Wp,C) tensor; without any of them the CLI refuses.
 """
 from __future__ import annotations
 
@@ -15,7 +17,8 @@ import os
 
 import torch
 
-from . import (evaluate_views, load_blender_data, load_checkpoint_into, load_config, model_from_config, render_settings)
+from . import (dino_model_from_config, evaluate_views, load_blender_data, load_checkpoint_into, load_config, model_from_config,
+               precompute_dino_features, render_settings)
 
 
 def main(argv=None):
@@ -30,6 +33,8 @@ def main(argv=None):
     ap.add_argument("--max-views", type=int, default=None)
     ap.add_argument("--ert", type=float, default=0.0)
     ap.add_argument("--dino-map", default=None)
+    ap.add_argument("--dino-weights", default=None, help="local transformers Dinov2Model checkpoint (dir or file) for the extractor of the config")
+    ap.add_argument("--dino-random-init", action="store_true", help="build the extractor with random weights (pipeline runs, features meaningless)")
     args = ap.parse_args(argv)
 
     cfg = load_config(args.config)
@@ -41,10 +46,18 @@ def main(argv=None):
     dino = None
     dino_dim = 128 if cfg.get("model", {}).get("dino_model_type") == "multi_scale" else 64
     if use_dino:
-        if not args.dino_map:
-            raise SystemExit("this config conditions on DINO features: pass --dino-map <tensor (1,Hp,Wp,C) saved with torch.save>")
-        fm = torch.load(args.dino_map, map_location="cpu", weights_only=True)
-        dino = dict(features=fm, pose=poses[0], focal=focal, H=H, W=W)       # eval uses view 0's map (train.py:203-208)
+        # the source view of every evaluation render is TRAINING view 0: its map and its pose (train.py:203-208)
+        tr_images, tr_poses, _ = load_blender_data(args.data, "train", img_size=cfg["data"].get("resolution"))
+        if args.dino_map:
+            fm = torch.load(args.dino_map, map_location="cpu", weights_only=True)
+        elif args.dino_weights or args.dino_random_init:
+            extractor = dino_model_from_config(cfg, weights=args.dino_weights).cuda()
+            fm = precompute_dino_features(extractor, tr_images[:1]).float()
+            del extractor
+        else:
+            raise SystemExit("this config conditions on DINO features: pass --dino-weights <local Dinov2Model checkpoint> (or --dino-random-init), "
+                             "or --dino-map <tensor (1,Hp,Wp,C) saved with torch.save>")
+        dino = dict(features=fm[:1], pose=tr_poses[0], focal=focal, H=H, W=W)
         dino_dim = int(fm.shape[-1])
     model = model_from_config(cfg, dino_dim=dino_dim, mma_mode=args.mode)
     if args.checkpoint:

@@ -1,5 +1,5 @@
 """python -m nerf_few_shot_limitations_amd.train_cli --config experiments/baseline.yaml --data data/nerf_synthetic/lego \\
-        [--epochs N] [--mode bf16|f16|f32] [--out DIR] [--dino-maps maps.pt] [--seed 0]
+        [--epochs N] [--mode bf16|f16|f32] [--out DIR] [--checkpoint CKPT] [--dino-weights DIR | --dino-maps maps.pt] [--seed 0]
 
 The training run of `NeRFDINOTrainer` (src/training/train.py:244-292 `train_step`, :344-372 `train`) as a command on the
 HIP path: the YAML loads unchanged; per epoch and training view the rays are cast at the progressive schedule's
@@ -9,10 +9,22 @@ rgb_weight * mse -> backward -> Adam(lr, weight_decay) -- with MultiStepLR betwe
 `output.val_freq` epochs on the fused renderer (`evaluate_views`) and checkpoints under the reference's key names
 (:374-389, readable by evaluate.py:22-33 and by evaluate_cli).
 
-use_dino configs condition on the DINOv2 feature map of every training view (train.py:153-165), which cannot be produced
-offline: pass --dino-maps with a tensor (V,Hp,Wp,C) saved by torch.save, one map per training view; the features of a
-sample are fetched by projection into the view being trained on (:203-214) and carry no gradient.
-wandb, LPIPS and the DINO/LoRA optimiser are not part of this command.
+Objective.  The step minimises `loss.rgb_weight * mse(rgb, target)` -- exactly what the reference's training loss returns:
+train.py:27-44 (the `NeRFLoss` class train.py defines and uses) computes only that term; `loss.depth_weight` /
+`loss.reg_weight` of the YAMLs are read into the constructor and never used there.  (nerf_mlp.NeRFLoss, a different class the
+trainer does not import, adds mean(weights^2); tests/test_gpu_training.py covers it through the autograd route.)
+
+use_dino configs condition on the DINOv2 feature map of every training view.  As in train.py:158-169 the maps are computed ONCE,
+under no_grad, by the extractor the config names (config.dino_model_from_config: SpatialDINOFeatures or
+MultiScaleDINOFeatures with LoRA wrappers) -- from --dino-weights (a local transformers Dinov2Model checkpoint; the weights are
+not available offline) or, to exercise the pipeline without them, --dino-random-init; --dino-maps takes precomputed maps
+(V,Hp,Wp,C) instead.  The features of a sample are fetched by projection into the view being trained on (:203-214).  Because the
+maps are constants, no gradient reaches the extractor -- in the reference too: its LoRA matrices sit in the optimizer
+(train.py:105-110) but never receive one.
+
+--checkpoint resumes a run: weights, Adam moments and step count, epoch counter and best PSNR (the reference's train.py saves
+these keys, :374-389, but has no resume path); the LR schedule is a function of the epoch.  wandb and LPIPS are not part of
+this command.
 """
 from __future__ import annotations
 
@@ -26,8 +38,8 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from . import (evaluate_views, get_rays, load_blender_data, load_checkpoint_into, load_config, model_from_config, render_settings,
-               sample_points_along_rays)
+from . import (dino_model_from_config, evaluate_views, get_rays, load_blender_data, load_checkpoint_into, load_config, model_from_config,
+               precompute_dino_features, render_settings, sample_points_along_rays)
 from .renderer import make_dino
 from .training import FusedStep
 
@@ -108,11 +120,30 @@ def save_checkpoint(path, model, step, epoch, best_psnr, cfg):
     """train.py:374-389's dictionary: `nerf_model_state_dict` is what evaluate.py:27 / load_checkpoint_into read."""
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     opt = step.opt
+    o = cfg["optimizer"]
     torch.save({"epoch": epoch, "best_psnr": best_psnr,
                 "nerf_model_state_dict": {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                # flat-vector Adam state (training.Adam; layout = include/nerfhip.h's flat parameter order), restored by --checkpoint
                 "optimizer_state_dict": {"step": opt.step_count, "exp_avg": None if opt.exp_avg is None else opt.exp_avg.cpu(),
                                          "exp_avg_sq": None if opt.exp_avg_sq is None else opt.exp_avg_sq.cpu(), "lr": opt.lr},
+                # MultiStepLR is a pure function of the epoch (lr_at): its state is the epoch counter
+                "scheduler_state_dict": {"last_epoch": epoch + 1, "milestones": list(o["lr_milestones"]), "gamma": float(o["lr_gamma"])},
                 "config": cfg}, path)
+
+
+def resume_from(ckpt, model, step):
+    """Restore what save_checkpoint wrote beyond the weights: Adam moments + step count; returns (first epoch to run, best PSNR).
+    A checkpoint without them (e.g. one written by the reference) resumes the weights only, from epoch 0."""
+    os_ = ckpt.get("optimizer_state_dict") if isinstance(ckpt, dict) else None
+    start, best = 0, 0.0
+    if isinstance(os_, dict) and os_.get("exp_avg") is not None and "step" in os_:
+        fp, flat = step.opt._buffers()
+        if os_["exp_avg"].numel() == flat.numel():
+            step.opt.exp_avg.copy_(os_["exp_avg"].to(flat.device))
+            step.opt.exp_avg_sq.copy_(os_["exp_avg_sq"].to(flat.device))
+            step.opt.step_count = int(os_["step"])
+            start, best = int(ckpt.get("epoch", -1)) + 1, float(ckpt.get("best_psnr", 0.0))
+    return start, best
 
 
 def main(argv=None):
@@ -122,8 +153,10 @@ def main(argv=None):
     ap.add_argument("--epochs", type=int, default=None, help="default: training.epochs of the config")
     ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--out", default=None, help="default: output.save_dir of the config")
-    ap.add_argument("--checkpoint", default=None, help="resume the model weights from this file")
-    ap.add_argument("--dino-maps", default=None)
+    ap.add_argument("--checkpoint", default=None, help="resume from this file: weights, Adam moments / step, epoch and best PSNR")
+    ap.add_argument("--dino-maps", default=None, help="precomputed feature maps (V,Hp,Wp,C), torch.save'd, one per training view")
+    ap.add_argument("--dino-weights", default=None, help="local transformers Dinov2Model checkpoint (dir or file) for the extractor of the config")
+    ap.add_argument("--dino-random-init", action="store_true", help="build the extractor with random weights (pipeline runs, features meaningless)")
     ap.add_argument("--max-test-views", type=int, default=None)
     ap.add_argument("--max-batches", type=int, default=None, help="stop every epoch after this many ray batches (smoke runs)")
     ap.add_argument("--seed", type=int, default=0)
@@ -161,26 +194,34 @@ def main(argv=None):
     use_dino = bool(cfg.get("model", {}).get("use_dino", True))
     dino_maps, dino_dim = None, 64
     if use_dino:
-        if not args.dino_maps:
-            raise SystemExit("this config conditions on DINO features: pass --dino-maps <tensor (V,Hp,Wp,C) saved with torch.save>, one map "
-                             "per training view")
-        dino_maps = torch.load(args.dino_maps, map_location="cpu", weights_only=True).float().to(dev)
+        if args.dino_maps:
+            dino_maps = torch.load(args.dino_maps, map_location="cpu", weights_only=True).float().to(dev)
+        elif args.dino_weights or args.dino_random_init:
+            extractor = dino_model_from_config(cfg, weights=args.dino_weights).to(dev)           # train.py:57-75
+            dino_maps = precompute_dino_features(extractor, torch.stack(images)[..., :3]).float()   # train.py:158-169: once, under no_grad
+            del extractor
+        else:
+            raise SystemExit("this config conditions on DINO features: pass --dino-weights <local Dinov2Model checkpoint> (or --dino-random-init), "
+                             "or --dino-maps <tensor (V,Hp,Wp,C) saved with torch.save>, one map per training view")
         if dino_maps.dim() != 4 or dino_maps.shape[0] < len(images):
             raise SystemExit("--dino-maps must hold one (Hp,Wp,C) map per training view")
         dino_dim = int(dino_maps.shape[-1])
     model = model_from_config(cfg, dino_dim=dino_dim, mma_mode=args.mode)
-    if args.checkpoint:
-        load_checkpoint_into(model, torch.load(args.checkpoint, map_location="cpu", weights_only=True))
+    ckpt = torch.load(args.checkpoint, map_location="cpu", weights_only=True) if args.checkpoint else None
+    if ckpt is not None:
+        load_checkpoint_into(model, ckpt)
     model = model.to(dev).train()
     o, lw = cfg["optimizer"], cfg.get("loss", {})
     step = FusedStep(model, lr=float(o["lr"]), weight_decay=float(o["weight_decay"]), rgb_weight=float(lw.get("rgb_weight", 1.0)),
                      white_bkgd=rs["white_bkgd"], data_parallel=world > 1)
     gen = torch.Generator(device=dev)
     gen.manual_seed(args.seed)
-    best, log = 0.0, []
+    best, log, first_epoch = 0.0, [], 0
+    if ckpt is not None:
+        first_epoch, best = resume_from(ckpt, model, step)
     targets = test_images.permute(0, 2, 3, 1).contiguous()
     eval_dino = dict(features=dino_maps[0:1], pose=poses[0], focal=focal, H=H, W=W) if use_dino else None      # train.py:203-208
-    for epoch in range(epochs):
+    for epoch in range(first_epoch, epochs):
         step.opt.lr = lr_at(cfg, epoch)
         t0 = time.perf_counter()
         loss, samples = train_epoch(step, cfg, epoch, images, poses, H, W, focal, rs["near"], rs["far"], gen, dino_maps, args.max_batches, rank, world)

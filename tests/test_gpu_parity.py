@@ -309,8 +309,12 @@ def test_render_v3_end_to_end_golden(N, golden, pmode):
         assert maxdiff(out["rgb"], g[f"v3_fog_{tag}_rgb"]) <= TOL
         assert maxdiff(out["depth"], g[f"v3_fog_{tag}_depth"]) <= TOL
         assert maxdiff(out["weights"], g[f"v3_fog_{tag}_w"]) <= TOL
+    # measured (profiles/r02_mode_error_report.txt): f16 rgb 9.0e-4 / depth 1.7e-3 / 77.8 dB; bf16 25.1 dB (tail-rule flips)
+    out16 = N.render_rays(m, ro, rd, 2.0, 6.0, S, dino=dino, mma_mode="f16")
+    assert maxdiff(out16["rgb"], g["v3_fog_plain_rgb"]) <= 2e-3 and maxdiff(out16["depth"], g["v3_fog_plain_depth"]) <= 4e-3
+    assert O.psnr(out16["rgb"].cpu(), T(g["v3_fog_plain_rgb"])) > 74
     out16 = N.render_rays(m, ro, rd, 2.0, 6.0, S, dino=dino, mma_mode="bf16")
-    assert O.psnr(out16["rgb"].cpu(), T(g["v3_fog_plain_rgb"])) > 25
+    assert O.psnr(out16["rgb"].cpu(), T(g["v3_fog_plain_rgb"])) > 22
     with pytest.raises(ValueError):
         N.render_rays(m, ro, rd, 2.0, 6.0, S)                    # a use_dino model without its side channel
 
@@ -406,16 +410,28 @@ def test_render_vs_oracle_100x100x32(N, pmode):
     # function of sigma_last (1 if sigma_last>0 else 0): on rays whose last sample has sigma ~ 0 any rounding
     # flips a weight of size T_last.  Rays are therefore split into "stable" (|sigma_last| clearly away from
     # 0 in the oracle) and the rest; bounds are asserted on the stable ones, PSNR on the whole frame.
+    # Bounds = 2x the measured error, PSNR floors = measured - 3 dB (profiles/r02_mode_error_report.txt):
+    #   f16  : stable rgb max 5.6e-3, median 3.3e-4, depth 3.3e-2, 47.5 dB, PSNR delta vs a common ground truth 0.0046 dB
+    #   bf16 : stable rgb max 4.3e-2, median 3.5e-3, depth 2.7e-1, 39.7 dB, PSNR delta 0.033 dB
+    # BASELINE.json's 0.01 dB bar is met by f16 (and the parity modes), not by bf16.
+    if pmode != "f32":
+        return
     pts_last = ro.reshape(-1, 3) + rd.reshape(-1, 3) * 6.0
     sig_last = O.mlp_v1(p, O.positional_encoding(pts_last, 10))[:, 3]
     stable = sig_last.abs() > 0.5
     assert stable.float().mean() > 0.5
-    for mode, tol, min_psnr in (("f16", 2e-2, 40.0), ("bf16", 2e-1, 28.0)):
+    gt = O.render_rays(p, "v1", ro, rd, 2.0, 6.0, 2 * S)["rgb"]            # common ground truth: the same rays with twice the samples
+    ps_ref = O.psnr(ref["rgb"], gt)
+    for mode, tol, dtol, med, min_psnr, max_delta in (("f16x3", 1.2e-5, 7e-5, 1e-6, 122.0, 1e-4), ("f16", 1.2e-2, 7e-2, 7e-4, 44.4, 0.01),
+                                                     ("bf16", 9e-2, 5.5e-1, 7e-3, 36.7, 0.07)):
         rgb_m, depth_m = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, mma_mode=mode)
         err = (rgb_m.cpu() - ref["rgb"]).abs().max(-1).values
+        derr = (depth_m.cpu() - ref["depth"]).abs()
         assert float(err[stable].max()) <= tol, (mode, float(err[stable].max()))
-        assert float(err.median()) <= tol / 20
-        assert O.psnr(rgb_m.cpu(), ref["rgb"]) > min_psnr
+        assert float(derr[stable].max()) <= dtol, (mode, float(derr[stable].max()))
+        assert float(err.median()) <= med, (mode, float(err.median()))
+        assert O.psnr(rgb_m.cpu(), ref["rgb"]) > min_psnr, (mode, O.psnr(rgb_m.cpu(), ref["rgb"]))
+        assert abs(O.psnr(rgb_m.cpu(), gt) - ps_ref) <= max_delta, (mode, abs(O.psnr(rgb_m.cpu(), gt) - ps_ref))
 
 
 def test_camera_mode_equals_explicit_rays_bitwise(N):
@@ -613,7 +629,10 @@ def test_full_frame_properties_800x800x64(N):
     assert torch.equal(band_rgb, rgb[b0:b1]) and torch.equal(band_depth, depth[b0:b1])
     ro, rd = O.get_rays(H, W, O.focal_for(W), c2w)
     ref = O.render_rays(p, "v1", ro.reshape(-1, 3)[b0:b1], rd.reshape(-1, 3)[b0:b1], 2.0, 6.0, S)
-    assert O.psnr(band_rgb.cpu(), ref["rgb"]) > 25                  # bf16 frame vs fp32 oracle (see the tail-rule note above)
+    assert O.psnr(band_rgb.cpu(), ref["rgb"]) > 36                  # bf16 frame vs fp32 oracle: measured 39.0 dB (f16: 68.4; see the tail-rule note above)
+    m16, _ = model_v1(N, "solid", "f16")
+    b16, _ = N.render_camera(m16, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ray_begin=b0, ray_end=b1)
+    assert O.psnr(b16.cpu(), ref["rgb"]) > 65
     for pmode in PARITY:
         m32, _ = model_v1(N, "solid", pmode)
         r32, d32 = N.render_camera(m32, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, ray_begin=b0, ray_end=b1)

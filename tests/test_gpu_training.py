@@ -807,7 +807,8 @@ _CFG = ("experiment: {{name: tiny}}\ndata: {{near: 2.0, far: 6.0, resolution: 16
         "nerf_model: {{pos_freq: {pf}, dir_freq: 4, hidden_dim: 256, num_layers: 8}}\n"
         "training: {{epochs: 3, batch_size: 64, progressive_schedule: {{epochs_0_50: [16, 16, 8], epochs_50_100: [16, 16, 12], epochs_100_plus: [16, 16, 16]}}}}\n"
         "optimizer: {{lr: 2.0e-3, weight_decay: 1.0e-6, lr_milestones: [2], lr_gamma: 0.5}}\nloss: {{rgb_weight: 1.0, depth_weight: 0.0, reg_weight: 0.0}}\n"
-        "output: {{save_dir: unused, val_freq: 2, save_freq: 3}}\n")
+        "output: {{save_dir: unused, val_freq: 2, save_freq: 3}}\n"
+        "dino_model: {{name: facebook/dinov2-small, lora_rank: 4, lora_alpha: 8, use_lora: true}}\n")
 
 
 @pytest.mark.parametrize("use_dino", [False, True])
@@ -846,6 +847,24 @@ def test_train_cli_runs_the_reference_schedule(N, tmp_path, use_dino):
     if not use_dino:                                                                              # the checkpoint feeds the evaluation command
         m = evaluate_cli.main(["--config", str(cfg), "--data", root, "--checkpoint", os.path.join(out, "best_tiny.pth"), "--mode", "f32"])
         assert m["views"] == 2 and abs(m["psnr"] - max(r.get("psnr", 0) for r in log)) < 1e-3
+        # --checkpoint resumes the run: epoch counter, Adam moments and step count continue (5 epochs = 3 + 2)
+        e3 = torch.load(os.path.join(out, "epoch_3.pth"), map_location="cpu", weights_only=True)
+        assert e3["epoch"] == 2 and e3["optimizer_state_dict"]["step"] > 0 and e3["scheduler_state_dict"]["last_epoch"] == 3
+        out2 = str(tmp_path / "run2")
+        log2 = train_cli.main(["--config", str(cfg), "--data", root, "--out", out2, "--mode", "f32", "--epochs", "5",
+                               "--checkpoint", os.path.join(out, "epoch_3.pth")])
+        assert [r["epoch"] for r in log2] == [4, 5] and log2[0]["lr"] == pytest.approx(1e-3)
+        steps_per_epoch = e3["optimizer_state_dict"]["step"] // 3
+        one = train_cli.main(["--config", str(cfg), "--data", root, "--out", str(tmp_path / "run3"), "--mode", "f32", "--epochs", "4",
+                              "--checkpoint", os.path.join(out, "epoch_3.pth")])
+        assert [r["epoch"] for r in one] == [4] and steps_per_epoch > 0
+        assert one[0]["loss"] == pytest.approx(log2[0]["loss"], rel=1e-6)                         # same restored state, same --seed: the resumed epoch is reproducible
+    else:
+        # the extractor route of train.py:57-75,158-169: maps produced once by the config's SpatialDINOFeatures (random init here:
+        # the DINOv2 weights are not available offline), then the same training loop
+        log3 = train_cli.main(["--config", str(cfg), "--data", root, "--out", str(tmp_path / "run_x"), "--mode", "f32", "--epochs", "1",
+                               "--checkpoint", str(tmp_path / "init.pth"), "--dino-random-init"])
+        assert [r["epoch"] for r in log3] == [1] and np.isfinite(log3[0]["loss"])
 
 
 def test_train_cli_schedule_and_lr_rules():

@@ -10,7 +10,8 @@ NeRF MLP (nerf_model.NeRFMLP, 951 808 FLOP per ray-sample), deterministic random
 --scaling weak (default): one step renders n_gpus views of the sensor: every view's rays are cut into 16-row pixel tiles
 dealt round-robin over the ranks, so per-GPU work is one frame's worth of rays whatever N is; each rank renders its
 tiles of ALL views with ONE kernel launch straight into the gather buffer and the tiles are exchanged with ONE RCCL
-all_gather per step so that every rank holds all frames.  --scaling strong: ONE view per step cut over the ranks
+all_gather per step so that every rank holds all frames; the all_gather of step i runs on RCCL's stream while step i+1 renders
+(two gather buffers; --no-overlap serialises them).  --scaling strong: ONE view per step cut over the ranks
 (BASELINE.json config 5's shape with --samples 128).  Whichever is the headline, the other one is measured too (a few
 steps after the timed region) and reported as `strong_scaling` / `weak_scaling`; the all_gather is timed separately
 (`gather_ms`).  Inputs are generated in-kernel (camera mode): nothing is read from the host in the timed region.
@@ -100,6 +101,7 @@ def main():
     ap.add_argument("--tile-rows", type=int, default=0, help="rows per pixel tile; 0 = largest <= 16 that deals the tiles evenly")
     ap.add_argument("--no-train", action="store_true", help="skip the optimisation-step timing appended as 'training' (N=1 only)")
     ap.add_argument("--no-extras", action="store_true", help="skip the parity_mode / ert legs (N=1 only)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the all_gather of a step with the next step's render")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
     args = ap.parse_args()
 
@@ -176,11 +178,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(job, steps, warmup):
-        """`warmup` untimed + `steps` timed steps of one job: (wall seconds [max over ranks], mean kernel ms, mean gather ms)."""
+    def run(n_views, steps, warmup, overlap):
+        """`warmup` untimed + `steps` timed steps: (wall seconds [max over ranks], mean kernel ms, mean gather ms or None, rays/launch).
+        overlap (N > 1): two jobs with their own gather buffers take turns; the all_gather of step i is enqueued asynchronously (RCCL
+        runs it on its own stream, after the render it depends on) while step i+1 renders -- every step still ends with every rank
+        holding every frame, the exchange just no longer sits between two renders.  A buffer is rendered into again only after the
+        gather that read it has completed (work.wait() orders the render stream behind it)."""
+        jobs = [make_job(n_views) for _ in range(2 if (overlap and world > 1) else 1)]
+        pending = [None] * len(jobs)
+        frames = [None] * len(jobs)
         kev, gev = [], []
 
-        def step(timed):
+        def step(i, timed):
+            k = i % len(jobs)
+            job = jobs[k]
+            if pending[k] is not None:
+                pending[k].wait()                          # the previous gather out of this job's buffer
+                pending[k] = None
             if timed:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
                 e0.record()
@@ -189,19 +203,31 @@ def main():
                 e1.record()
             if world > 1:
                 if backend != "nccl":
-                    tiles.gather_frames(job.buf.cpu(), H * W, tile_rays)
+                    frames[k] = tiles.gather_frames(job.buf.cpu(), H * W, tile_rays)
+                elif len(jobs) == 1:
+                    frames[k] = tiles.gather_frames(job.buf, H * W, tile_rays)          # ONE all_gather (RCCL) + the view into frame order
                 else:
-                    tiles.gather_frames(job.buf, H * W, tile_rays)         # ONE all_gather (RCCL) + the view into frame order
+                    if frames[k] is None:
+                        frames[k] = torch.empty((world,) + tuple(job.buf.shape), dtype=job.buf.dtype, device=dev)
+                    pending[k] = dist.all_gather_into_tensor(frames[k].view(-1), job.buf.view(-1), async_op=True)
             if timed:
                 e2.record()
                 kev.append((e0, e1)); gev.append((e1, e2))
 
-        for _ in range(warmup):
-            step(False)
+        def drain():
+            for k in range(len(jobs)):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+
+        for i in range(warmup):
+            step(i, False)
+        drain()
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step(True)
+        for i in range(steps):
+            step(warmup + i, True)
+        drain()
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -209,15 +235,25 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         kms = sum(a.elapsed_time(b) for a, b in kev) / max(len(kev), 1)
-        gms = sum(a.elapsed_time(b) for a, b in gev) / max(len(gev), 1) if world > 1 else None
-        return dt, kms, gms
+        gms = sum(a.elapsed_time(b) for a, b in gev) / max(len(gev), 1) if (world > 1 and len(jobs) == 1) else None
+        return dt, kms, gms, jobs[0].rays_per_launch
 
     views_main = world if args.scaling == "weak" else 1
-    job = make_job(views_main)
-    dt, kernel_ms, gather_ms = run(job, args.steps, args.warmup)
+    overlap = world > 1 and backend == "nccl" and not args.no_overlap
+    try:
+        dt, kernel_ms, gather_ms, rays_per_launch = run(views_main, args.steps, args.warmup, overlap)
+    except Exception as e:                                  # the serial exchange is the conservative form: fall back to it
+        if not overlap:
+            raise
+        print(f"[bench] rank {rank}: overlapped gather failed ({type(e).__name__}: {e}); repeating with --no-overlap", file=sys.stderr, flush=True)
+        overlap = False
+        dt, kernel_ms, gather_ms, rays_per_launch = run(views_main, args.steps, args.warmup, overlap)
     print(f"[bench] rank {rank}: timed region done", file=sys.stderr, flush=True)
+    if world > 1 and gather_ms is None and args.other_steps > 0:
+        # the exchange on its own: a few steps with the all_gather NOT overlapped, timed with events around it
+        _, _, gather_ms, _ = run(views_main, min(args.other_steps, 5), 1, False)
 
-    samples_per_launch = job.rays_per_launch * S
+    samples_per_launch = rays_per_launch * S
     samples_per_step = views_main * H * W * S                     # all ranks together
     value = samples_per_step * args.steps / dt / 1e6
     achieved = samples_per_launch * flops_per_sample / (kernel_ms * 1e-3) / 1e12
@@ -242,8 +278,10 @@ def main():
         "dtype": args.mode, "data": "synthetic",
         "config": {"workload": f"{H}x{W} camera frame x {S} samples/ray, NeRFMLP {args.net} 8x256, scene {args.scene}, "
                                f"{views_main} view(s)/step, {tile_rows}-row pixel tiles dealt round-robin over {world} GPU(s), one launch + one all_gather per step",
-                   "rays_per_gpu_per_step": job.rays_per_launch, "samples_per_ray": S, "ert_eps": args.ert,
-                   "flops_per_sample": flops_per_sample, "parallelism": f"pixel-tile x{world}"},
+                   "rays_per_gpu_per_step": rays_per_launch, "samples_per_ray": S, "ert_eps": args.ert,
+                   "flops_per_sample": flops_per_sample, "parallelism": f"pixel-tile x{world}",
+                   "gather": ("all_gather of step i overlapped with the render of step i+1 (two gather buffers)" if overlap else
+                              ("one all_gather between renders" if world > 1 else "none (one GPU)"))},
         "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.mode], "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -254,14 +292,14 @@ def main():
     if args.other_steps > 0 and world > 1:
         other = "strong" if args.scaling == "weak" else "weak"
         views_o = 1 if other == "strong" else world
-        job_o = make_job(views_o)
-        dto, kmo, gmo = run(job_o, args.other_steps, 2)
+        dto, kmo, gmo, rays_o = run(views_o, args.other_steps, 2, overlap)
+        if gmo is None:
+            _, _, gmo, _ = run(views_o, min(args.other_steps, 5), 1, False)
         out[f"{other}_scaling"] = {
             "workload": f"{views_o} view(s) of {H}x{W}x{S} per step cut over {world} GPU(s)", "steps": args.other_steps,
             "value": round(views_o * H * W * S * args.other_steps / dto / 1e6, 2), "unit": "M ray-samples/s",
             "ms_per_step": round(dto / args.other_steps * 1e3, 4), "kernel_ms": round(kmo, 4), "gather_ms": None if gmo is None else round(gmo, 4),
-            "rays_per_gpu_per_step": job_o.rays_per_launch}
-        del job_o
+            "rays_per_gpu_per_step": rays_o}
 
     single = rank == 0 and world == 1
     if single and args.cpu_rows > 0:

@@ -1,47 +1,70 @@
-"""Blender-format dataset loader without torchvision (replaces
-src/models/data_loader.py:8-64).  Same signature, same return values:
+"""Blender-format dataset loader: the step right before the hot path.
+
+Interface of the reference's `load_blender_data` (src/models/data_loader.py:8-64) -- same arguments, same return values
 
     images (N,3,H,W) float32 in [0,1], poses (N,4,4) float32, (H, W, focal)
 
-`T.Resize(dims, interpolation=LANCZOS)` + `T.ToTensor()` of the reference are `PIL.Image.resize` + a uint8/255
-conversion; focal = 0.5*W/tan(0.5*camera_angle_x)*focal_scale (data_loader.py:62).  The reference module cannot be
-imported offline (it needs torchvision), so this restatement is unpinned by reference outputs; it is covered by a
-procedurally generated fixture in tests/test_host_glue.py.
+-- on a different pipeline: the split's geometry (target size, focal scale) is resolved once from the first frame, the PNGs are
+decoded and LANCZOS-resized by a thread pool (PIL releases the GIL while decoding) straight into ONE preallocated uint8 block,
+and the block is converted to float once (on `device`, if one is given: a single host-to-device copy of the uint8 data, a quarter
+of the float bytes).  No torchvision.
+
+What must agree with the reference, and does by construction: alpha is dropped, not composited (`.convert("RGB")`, :33);
+`T.Resize((h, w), LANCZOS)` is `PIL.Image.resize((w, h), LANCZOS)`; `T.ToTensor()` is uint8 / 255;
+focal = 0.5 * W / tan(0.5 * camera_angle_x) * focal_scale with focal_scale = img_size / W_orig, or 0.5 for half_res (:37-42,62).
+The reference module needs torchvision and cannot be imported offline: outputs are unpinned by it; the behaviour above is
+tested on a generated scene (tests/test_host_glue.py).
 """
 from __future__ import annotations
 
 import json
 import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 import torch
 from PIL import Image
 
 
-def load_blender_data(basedir, split="train", img_size=None, half_res=False):
+def _split_meta(basedir, split):
     with open(os.path.join(basedir, f"transforms_{split}.json"), "r") as f:
         meta = json.load(f)
-    images, poses = [], []
-    focal_scale = 1.0
-    for frame in meta["frames"]:
-        img_path = os.path.join(basedir, frame["file_path"] + ".png")
-        if not os.path.exists(img_path):
-            raise FileNotFoundError(f"Image not found: {img_path}")
-        img = Image.open(img_path).convert("RGB")                      # data_loader.py:33 (alpha dropped, not composited)
-        W_orig, H_orig = img.size
-        if img_size:
-            dims, focal_scale = (img_size, img_size), img_size / W_orig   # :37-39
-        elif half_res:
-            dims, focal_scale = (H_orig // 2, W_orig // 2), 0.5            # :40-42
-        else:
-            dims, focal_scale = (H_orig, W_orig), 1.0
-        if (dims[0], dims[1]) != (H_orig, W_orig):
-            img = img.resize((dims[1], dims[0]), Image.LANCZOS)            # T.Resize takes (h, w), PIL takes (w, h)
-        arr = np.asarray(img, dtype=np.uint8)
-        images.append(torch.from_numpy(arr.copy()).permute(2, 0, 1).float().div(255.0))   # T.ToTensor()
-        poses.append(torch.from_numpy(np.array(frame["transform_matrix"], dtype=np.float32)))
-    images = torch.stack(images)
-    poses = torch.stack(poses)
-    _, _, H, W = images.shape
-    focal = 0.5 * W / np.tan(0.5 * meta["camera_angle_x"]) * focal_scale
-    return images, poses, (H, W, float(focal))
+    paths = [os.path.join(basedir, fr["file_path"] + ".png") for fr in meta["frames"]]
+    for p in paths:
+        if not os.path.exists(p):
+            raise FileNotFoundError(f"Image not found: {p}")
+    poses = np.asarray([fr["transform_matrix"] for fr in meta["frames"]], dtype=np.float32).reshape(-1, 4, 4)
+    return paths, poses, float(meta["camera_angle_x"])
+
+
+def _geometry(first_png, img_size, half_res):
+    """(H, W, focal_scale) of the loaded images from the size of the stored ones (data_loader.py:35-44)."""
+    with Image.open(first_png) as im:
+        w0, h0 = im.size
+    if img_size:
+        return int(img_size), int(img_size), img_size / w0
+    if half_res:
+        return h0 // 2, w0 // 2, 0.5
+    return h0, w0, 1.0
+
+
+def _decode_into(block, i, path, H, W):
+    with Image.open(path) as im:
+        im = im.convert("RGB")
+        if im.size != (W, H):
+            im = im.resize((W, H), Image.LANCZOS)
+        block[i] = np.asarray(im, dtype=np.uint8)
+
+
+def load_blender_data(basedir, split="train", img_size=None, half_res=False, device=None, workers=8):
+    paths, poses, angle = _split_meta(basedir, split)
+    H, W, focal_scale = _geometry(paths[0], img_size, half_res)
+    block = np.empty((len(paths), H, W, 3), dtype=np.uint8)
+    with ThreadPoolExecutor(max_workers=max(1, min(workers, len(paths)))) as pool:
+        list(pool.map(lambda a: _decode_into(block, a[0], a[1], H, W), enumerate(paths)))
+    raw = torch.from_numpy(block)
+    if device is not None:
+        raw = raw.to(device)
+    images = raw.permute(0, 3, 1, 2).float().div_(255.0).contiguous()
+    focal = 0.5 * W / np.tan(0.5 * angle) * focal_scale
+    return images, torch.from_numpy(poses), (H, W, float(focal))

@@ -2,9 +2,13 @@
 PSNR / SSIM, PNG dumps -- what NeRFDINOTrainer.evaluate does around render_rays (src/training/train.py:294-342) with
 torchmetrics / imageio, neither of which is installed here.
 
-PSNR = -10 log10(mse), data range 1 (train_multiscale.py:294-295).  SSIM is the standard single-scale form
-(11x11 Gaussian window, sigma 1.5, K1=.01, K2=.03, data range 1), i.e. torchmetrics' defaults; LPIPS needs VGG weights
-that cannot be fetched offline and is not provided.  Metric parity with torchmetrics is unpinned (not importable).
+PSNR = -10 log10(mse), data range 1 (train_multiscale.py:294-295).  SSIM follows the algorithm of the metric the reference
+instantiates, `torchmetrics.StructuralSimilarityIndexMeasure()` with its defaults (train.py:100,328): single scale, 11x11
+Gaussian window of sigma 1.5, K1=.01, K2=.03, reflect-padded inputs, the padded border cropped from the index map before the
+mean, and -- because the reference passes no data_range -- the range taken from the data, max(pred range, target range).
+`ssim(..., data_range=1.0, crop_border=False)` gives the textbook form.  torchmetrics is not importable here, so parity with it is
+unpinned; tests/test_host_glue.py checks this code against an independent scipy restatement of the same definition.  LPIPS
+needs VGG weights that cannot be fetched offline and is not provided.
 """
 from __future__ import annotations
 
@@ -32,8 +36,8 @@ def _gauss_window(size=11, sigma=1.5, device=None):
     return (g[:, None] * g[None, :])[None, None]
 
 
-def ssim(pred: torch.Tensor, target: torch.Tensor, size=11, sigma=1.5) -> float:
-    """pred/target (H,W,3) or (3,H,W) in [0,1]."""
+def ssim(pred: torch.Tensor, target: torch.Tensor, size=11, sigma=1.5, data_range=None, crop_border=True) -> float:
+    """pred/target (H,W,3) or (3,H,W).  data_range=None: from the data, as the reference's default-constructed metric does."""
     def chw(t):
         t = t.float()
         return (t.permute(2, 0, 1) if t.shape[-1] == 3 and t.shape[0] != 3 else t)[None]
@@ -46,8 +50,12 @@ def ssim(pred: torch.Tensor, target: torch.Tensor, size=11, sigma=1.5) -> float:
     s_aa = F.conv2d(a_p * a_p, w, groups=c) - mu_a ** 2
     s_bb = F.conv2d(b_p * b_p, w, groups=c) - mu_b ** 2
     s_ab = F.conv2d(a_p * b_p, w, groups=c) - mu_a * mu_b
-    c1, c2 = 0.01 ** 2, 0.03 ** 2
+    if data_range is None:
+        data_range = float(torch.maximum(a.max() - a.min(), b.max() - b.min()).item())
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
     m = ((2 * mu_a * mu_b + c1) * (2 * s_ab + c2)) / ((mu_a ** 2 + mu_b ** 2 + c1) * (s_aa + s_bb + c2))
+    if crop_border and m.shape[-1] > 2 * pad and m.shape[-2] > 2 * pad:
+        m = m[..., pad:-pad, pad:-pad]
     return float(m.mean().item())
 
 

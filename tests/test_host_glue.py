@@ -61,3 +61,33 @@ def test_psnr_ssim_and_png(tmp_path):
     N.save_png(p, a)
     back = np.asarray(Image.open(p), np.float32) / 255
     assert back.shape == (24, 20, 3) and np.abs(back - a.numpy()).max() <= 1 / 255 + 1e-6
+
+
+def test_ssim_against_an_independent_restatement():
+    """The SSIM of evaluation.py against a scipy restatement of the same published definition (Wang et al. 2004, as the metric
+    the reference instantiates computes it: 11-tap Gaussian of sigma 1.5 applied separably with mirrored borders, K1 = .01,
+    K2 = .03, data range from the data, border of 5 pixels cropped from the index map).  torchmetrics itself is not importable
+    here: parity with it stays unpinned; this pins the arithmetic to the definition."""
+    from scipy.ndimage import correlate1d
+    rng = np.random.RandomState(3)
+    a = rng.rand(40, 33, 3).astype(np.float32) * 0.8 + 0.1
+    b = np.clip(a + 0.1 * rng.randn(40, 33, 3).astype(np.float32), 0, 1)
+    x = np.arange(11) - 5.0
+    g = np.exp(-(x ** 2) / (2 * 1.5 ** 2)); g /= g.sum()
+
+    def blur(img):                                             # per channel, rows then columns, mirrored (no edge repeat) borders
+        return correlate1d(correlate1d(img.astype(np.float64), g, axis=0, mode="mirror"), g, axis=1, mode="mirror")
+
+    def ref_ssim(p, t, data_range, crop):
+        c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+        mp, mt = blur(p), blur(t)
+        spp, stt, spt = blur(p * p) - mp ** 2, blur(t * t) - mt ** 2, blur(p * t) - mp * mt
+        m = ((2 * mp * mt + c1) * (2 * spt + c2)) / ((mp ** 2 + mt ** 2 + c1) * (spp + stt + c2))
+        if crop:
+            m = m[5:-5, 5:-5]
+        return float(m.mean())
+
+    dr = max(a.max() - a.min(), b.max() - b.min())
+    assert abs(N.ssim(torch.from_numpy(a), torch.from_numpy(b)) - ref_ssim(a, b, dr, True)) < 2e-6
+    assert abs(N.ssim(torch.from_numpy(a), torch.from_numpy(b), data_range=1.0, crop_border=False) - ref_ssim(a, b, 1.0, False)) < 2e-6
+    assert abs(N.ssim(torch.from_numpy(a).permute(2, 0, 1), torch.from_numpy(b).permute(2, 0, 1)) - ref_ssim(a, b, dr, True)) < 2e-6

@@ -508,6 +508,19 @@ def test_two_process_tile_render_and_gather(N, shape, tmp_path):
             assert np.array_equal(frames[v, :, :3], rgb.cpu().numpy()) and np.array_equal(frames[v, :, 3], depth.cpu().numpy()), (rank, v)
 
 
+def test_rccl_backend_single_rank(N):
+    """bench.py's collective calls on the real backend (RCCL) with a one-rank world: tests/rccl_worker.py."""
+    import os, socket, subprocess, sys
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tests", "rccl_worker.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_rgbd_rows_equal_separate_outputs_and_work_split_is_invisible(N):
     """(a) nrf_render_opts.out_rgbd: the (R,4) [r,g,b,depth] rows the tile jobs write equal the separate outputs bit for bit;
     (b) the samples-per-pass split of a launch (render_kernel: 32 rays x 1 sample, 16 x 2 or 8 x 4 per wave and pass, picked

@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
 
-    Pipe<WAVES> pipe;
+    Pipe<WAVES, false, Mode::kPinned> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 #ifdef NRF_YOUNG_PRIO
@@ -314,7 +314,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     ST(F_OX) = 0.f; ST(F_OY) = 0.f; ST(F_OZ) = 0.f; ST(F_DX) = 0.f; ST(F_DY) = 0.f; ST(F_DZ) = -1.f; ST(F_Z) = 1.f;
     load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
 
-    Pipe<WAVES, false> pipe;     // a wave that has run dry keeps computing (on stale inputs, storing nothing): the workgroup moves in lockstep anyway, and the skip paths cost registers in every layer
+    Pipe<WAVES, false, Mode::kPinned> pipe;     // a wave that has run dry keeps computing (on stale inputs, storing nothing): the workgroup moves in lockstep anyway, and the skip paths cost registers in every layer
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
-    Pipe<WAVES> pipe;
+    Pipe<WAVES, false, Mode::kPinned> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
     const int own = (NT == 2) ? h : 0;

@@ -82,7 +82,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // acquire(X) is called a few fragments BEFORE the reads of chunk X-1 are finished (dense() below), so that the
 // first fragments of chunk X are already in flight while the last MFMAs of chunk X-1 run: that is why the
 // slot recycled at the barrier is the one two chunks back, not one.
-template <int WAVES, bool CAN_SKIP = false>
+// ASM_DMA: issue the LDS-DMA as inline asm (the one-wave-per-SIMD modes: see dense_pinned()).
+template <int WAVES, bool CAN_SKIP = false, bool ASM_DMA = false>
 struct Pipe {
     static constexpr bool kCanSkip = CAN_SKIP;    // early-ray-termination build: a wave may sit out the math (see dense())
     static constexpr int kFragsPerWave = kChunkFrags / WAVES;    // glds instructions per wave per chunk
@@ -115,8 +116,21 @@ struct Pipe {
         const NRF_GLB char* g = src + (size_t)issue_chunk * kChunkBytes;
         NRF_LDS char* l = ring + issue_slot * kChunkBytes + wave_off;
 #pragma unroll
-        for (int i = 0; i < kFragsPerWave; ++i)
-            __builtin_amdgcn_global_load_lds((const NRF_GLB void*)(g + i * kFragBytes), (NRF_LDS void*)(l + i * kFragBytes), 16, 0, 0);
+        for (int i = 0; i < kFragsPerWave; ++i) {
+            if constexpr (ASM_DMA) {
+                // hipcc then tracks neither the DMA's vmcnt (waited for by hand in acquire()) nor -- the point -- an LDS access
+                // through a FLAT-encoded instruction, whose "pending flat" state makes its waitcnt pass answer the fragment reads
+                // that follow with lgkmcnt(0) instead of counted waits.  M0 (the DMA's LDS base) is saved and restored inside the
+                // statement.  (Measured: +1 % for the split-f16 kernel, -3 % for the two-waves-per-SIMD 16-bit kernels.)
+                const NRF_GLB char* gp = g + i * kFragBytes;
+                const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(l + i * kFragBytes));
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
+            } else {
+                __builtin_amdgcn_global_load_lds((const NRF_GLB void*)(g + i * kFragBytes), (NRF_LDS void*)(l + i * kFragBytes), 16, 0, 0);
+            }
+        }
         issue_chunk = (issue_chunk + 1 == n_chunks) ? 0u : issue_chunk + 1;
         issue_slot = (issue_slot + 1 == (uint32_t)kSlots) ? 0u : issue_slot + 1;
     }
@@ -142,6 +156,7 @@ struct Pipe {
 // ---------------------------------------------------------------------------
 struct ModeBF16 {
     static constexpr int SUB = 2;            // fragments per (m-tile, k-tile)
+    static constexpr bool kPinned = false;   // two waves per SIMD cover each other: hipcc's own schedule is the faster one
     static constexpr int TRIG = 1;           // v_sin on exactly reduced turns: error far below bf16 resolution (nets.hpp:encode3)
     static constexpr bool FAST_EXP = true;   // v_exp based exp/sigmoid in the compositor
     typedef bf16x8 frag_t;
@@ -165,6 +180,7 @@ struct ModeBF16 {
 
 struct ModeF16 {
     static constexpr int SUB = 2;
+    static constexpr bool kPinned = false;
     static constexpr int TRIG = 1;
     static constexpr bool FAST_EXP = false;
     typedef f16x8 frag_t;
@@ -188,6 +204,7 @@ struct ModeF16 {
 
 struct ModeF32 {
     static constexpr int SUB = 4;
+    static constexpr bool kPinned = false;   // 64-cycle MFMAs: the epilogue is 1 % of a tile
     static constexpr int TRIG = 0;           // ocml sincosf on the exact argument
     static constexpr bool FAST_EXP = false;
     typedef f32x4 frag_t;
@@ -217,6 +234,7 @@ struct ModeF32 {
 // mode, so the geometry is the fp32 mode's: 4 waves x 32 samples, one wave per SIMD.
 struct ModeF16X3 {
     static constexpr int SUB = 4;
+    static constexpr bool kPinned = true;    // one wave per SIMD: the step order and the epilogue slices are pinned (dense_pinned)
     static constexpr int TRIG = 2;           // polynomial sin on exactly reduced turns: <= 2e-7 abs (nets.hpp:encode3)
     static constexpr bool FAST_EXP = false;
     typedef f16x8 frag_t;
@@ -248,6 +266,27 @@ struct ModeF16X3 {
             o.lo[s] = __builtin_bit_cast(f16x8, wl);
         }
         return o;
+    }
+    // one register pair (accumulator registers 2j, 2j+1) of a tile -> word j of its hi / lo operand images: the epilogue in
+    // eight slices, so that dense_pinned() can hand one slice to each of the next tile's first MFMA steps
+    template <bool RELU>
+    __device__ static __forceinline__ void to_act_pair(const f32x16& v, int j, Act& o) {
+        const int s = j >> 2, w = j & 3;
+        const float a = __builtin_amdgcn_fmed3f(v[2 * j], RELU ? 0.0f : -65504.0f, 65504.0f);
+        const float b = __builtin_amdgcn_fmed3f(v[2 * j + 1], RELU ? 0.0f : -65504.0f, 65504.0f);
+        const f32x2 ab = {a, b};
+        const f16x2 hh = __builtin_convertvector(ab, f16x2);
+        const f32x2 hf = __builtin_convertvector(hh, f32x2);
+        const f32x2 rest = {__fsub_rn(a, hf[0]), __fsub_rn(b, hf[1])};
+        int nh = __builtin_bit_cast(int, hh), nl = __builtin_bit_cast(int, __builtin_convertvector(rest, f16x2));
+        // the words are first USED by the next layer: without this (empty, opaque) statement LLVM sinks the whole slice down to
+        // that use, across the step fences, and the epilogues of several tiles pile up between two MFMAs again
+        asm volatile("" : "+v"(nh), "+v"(nl));
+        i32x4 wh = __builtin_bit_cast(i32x4, o.hi[s]), wl = __builtin_bit_cast(i32x4, o.lo[s]);
+        wh[w] = nh;
+        wl[w] = nl;
+        o.hi[s] = __builtin_bit_cast(f16x8, wh);
+        o.lo[s] = __builtin_bit_cast(f16x8, wl);
     }
 };
 
@@ -328,25 +367,98 @@ __device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,
     fin(std::integral_constant<int, MT - 1>{}, acc[(MT - 1) & 1]);
 }
 
+// The same layer for the modes that run ONE wave per SIMD (Mode::kPinned).  There nothing covers what the wave itself does not
+// overlap, and hipcc's schedule does two things that cost a quarter of the MFMA pipe: it sinks every fragment read to just in
+// front of its MFMA, and it gathers the epilogues of several tiles into single blocks of ~280 VALU instructions between two
+// MFMAs.  Here every fragment step is fenced (__builtin_amdgcn_sched_barrier): step f = the MFMAs of fragment f, the read of
+// fragment f + PF, and ONE slice (a register pair) of the previous tile's epilogue, `fin(m, acc, j)`, j = 0..7 -- so the VALU work
+// rides in the shadow of the MFMAs (an MFMA holds the issue port for 8 of its 32 cycles).  The bias of the tile after next is
+// fetched in the step behind the last slice (its accumulator set is free from then on).  With the LDS-DMA issued as inline asm
+// (Pipe<..., ASM_DMA>) hipcc's waitcnt pass sees a pure in-order ds_read stream and emits counted lgkmcnt waits.
+template <class Mode, int KT, int MT, int NT, class P, class FinSlice>
+__device__ __forceinline__ void dense_pinned(P& pipe, const NRF_LDS float* bias, int h,
+                                             const typename Mode::Act (&in)[KT][NT], FinSlice&& fin) {
+    constexpr int PER_M = KT * Mode::SUB;
+    constexpr int NF = MT * PER_M;
+    constexpr int PF = NF < kPrefetch ? NF : kPrefetch;
+    constexpr int EPI = PER_M > kEpilogueAt + 1 ? kEpilogueAt : 1;      // first slice step: tile m-1's last MFMAs have drained
+    constexpr int ROOM = PER_M - EPI - 1;                               // steps that may carry slices (one more is the bias step)
+    static_assert(ROOM >= 1, "layer too short for the sliced epilogue");
+    constexpr int SPS = (8 + ROOM - 1) / ROOM;                          // slices per step
+    constexpr int NSTEP = (8 + SPS - 1) / SPS;
+    constexpr int BIAS_AT = EPI + NSTEP;
+    static_assert(BIAS_AT < PER_M, "no step left for the bias fetch");
+    typedef typename Mode::frag_t frag_t;
+    frag_t fr[PF];
+    auto read = [&](auto g_) -> frag_t {
+        constexpr int g = decltype(g_)::value;
+        if constexpr (g % kChunkFrags == 0) pipe.acquire((g / kChunkFrags) & 1);
+        return *(const NRF_LDS frag_t*)(pipe.base[(g / kChunkFrags) & 1] + (g % kChunkFrags) * kFragBytes);
+    };
+    static_for<PF>([&](auto i_) { fr[decltype(i_)::value] = read(i_); });
+    f32x16 acc[2][NT];
+    load_bias(acc[0][0], bias, h);
+#pragma unroll
+    for (int n = 1; n < NT; ++n) acc[0][n] = acc[0][0];
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NF>([&](auto f_) {
+        constexpr int f = decltype(f_)::value;
+        constexpr int m = f / PER_M, rem = f % PER_M, t = rem / Mode::SUB, s = rem % Mode::SUB;
+        const frag_t a = fr[f % PF];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Mode::mma(acc[m & 1][n], a, in[t][n], s);
+        if constexpr (f + PF < NF) fr[f % PF] = read(std::integral_constant<int, f + PF>{});
+        if constexpr (m > 0 && rem >= EPI && rem < EPI + NSTEP) {
+            static_for<SPS>([&](auto k_) {
+                constexpr int j = (rem - EPI) * SPS + decltype(k_)::value;
+                if constexpr (j < 8) fin(std::integral_constant<int, m - 1>{}, acc[(m - 1) & 1], std::integral_constant<int, j>{});
+            });
+        }
+        if constexpr (rem == BIAS_AT && m + 1 < MT) {
+            load_bias(acc[(m + 1) & 1][0], bias + 32 * (m + 1), h);
+#pragma unroll
+            for (int n = 1; n < NT; ++n) acc[(m + 1) & 1][n] = acc[(m + 1) & 1][0];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    static_for<8>([&](auto j_) { fin(std::integral_constant<int, MT - 1>{}, acc[(MT - 1) & 1], j_); });
+}
+
 // layer with an activation, producing the next layer's operand tiles
 template <class Mode, int KT, int MT, int NT, bool RELU, class P>
 __device__ __forceinline__ void dense_act(P& pipe, const NRF_LDS float* bias, int h,
                                           const typename Mode::Act (&in)[KT][NT], typename Mode::Act (&out)[MT][NT]) {
-    dense<Mode, KT, MT, NT>(pipe, bias, h, in, [&](auto m_, f32x16(&acc)[NT]) {
-        constexpr int m = decltype(m_)::value;
+    if constexpr (Mode::kPinned) {
+        dense_pinned<Mode, KT, MT, NT>(pipe, bias, h, in, [&](auto m_, f32x16(&acc)[NT], auto j_) {
+            constexpr int m = decltype(m_)::value;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) out[m][n] = Mode::template to_act<RELU>(acc[n]);
-    });
+            for (int n = 0; n < NT; ++n) Mode::template to_act_pair<RELU>(acc[n], decltype(j_)::value, out[m][n]);
+        });
+    } else {
+        dense<Mode, KT, MT, NT>(pipe, bias, h, in, [&](auto m_, f32x16(&acc)[NT]) {
+            constexpr int m = decltype(m_)::value;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) out[m][n] = Mode::template to_act<RELU>(acc[n]);
+        });
+    }
 }
 
 // head layer: one output tile, raw accumulators back to the caller
 template <class Mode, int KT, int NT, class P>
 __device__ __forceinline__ void dense_head(P& pipe, const NRF_LDS float* bias, int h,
                                            const typename Mode::Act (&in)[KT][NT], f32x16 (&out)[NT]) {
-    dense<Mode, KT, 1, NT>(pipe, bias, h, in, [&](auto, f32x16(&acc)[NT]) {
+    if constexpr (Mode::kPinned) {
+        dense_pinned<Mode, KT, 1, NT>(pipe, bias, h, in, [&](auto, f32x16(&acc)[NT], auto j_) {
+            constexpr int j = decltype(j_)::value;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) out[n] = acc[n];
-    });
+            for (int n = 0; n < NT; ++n) { out[n][2 * j] = acc[n][2 * j]; out[n][2 * j + 1] = acc[n][2 * j + 1]; }
+        });
+    } else {
+        dense<Mode, KT, 1, NT>(pipe, bias, h, in, [&](auto, f32x16(&acc)[NT]) {
+#pragma unroll
+            for (int n = 0; n < NT; ++n) out[n] = acc[n];
+        });
+    }
 }
 
 constexpr __host__ __device__ int chunks_for(int frags) { return (frags + kChunkFrags - 1) / kChunkFrags; }

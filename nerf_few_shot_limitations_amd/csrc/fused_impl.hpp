@@ -16,9 +16,9 @@ namespace nrf {
 
 constexpr int kBiasMaxFloats = 4096;                                   // 16 KiB bias table
 constexpr int kLdsRing = kSlots * kChunkBytes;                         // 128 KiB
-constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64 + 4096;   // + ERT flags + depth-ladder cache (ray-queue kernel)
-constexpr int kLdsBytesQueue = kLdsBytes + 14 * 512 * 4;                // + per-lane ray state of the ray-queue kernel
-static_assert(kLdsBytesQueue <= 160 * 1024, "ray-queue kernel: LDS over budget (use a 6-slot ring)");
+constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64 + 4096;   // staged forward: ring + bias table (+ the renderers' vote flags and depth-ladder cache)
+constexpr int kLdsBytesQueue = kLdsBytes + 14 * 512 * 4;                // both renderers: + 14 floats of per-lane ray state for up to 512 threads
+static_assert(kLdsBytesQueue <= 160 * 1024, "renderers: LDS over budget (use a 6-slot ring)");
 
 struct NetArgs {
     const void* stream;
@@ -84,9 +84,10 @@ enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_NORM, F_Z, F_T, F_R, F_G, F_B, F_DE
 constexpr int kLadderLds = 1024;      // depth-ladder entries cached in LDS by the ray-queue kernel (per-lane sample indices gather from it)
 constexpr int kLdsState = kLdsRing + kBiasMaxFloats * 4 + 64 + kLadderLds * 4;     // byte offset of the state rows
 
-template <class Net, class Mode, int WAVES, int LP, int LD>
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P) {
-    constexpr int NT = 1;
+    static_assert(NT == 1 || NT == 2, "a wave marches 32 or 64 sample columns");
+    constexpr int COLS = 32 * NT;                  // sample columns of a wave: column q = c + 32 n sits on lanes c, c + 32 of operand tile n
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NRF_LDS char* lds = (NRF_LDS char*)smem;
     NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
@@ -105,24 +106,23 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
 
-    Pipe<WAVES, false, Mode::kPinned> pipe;
+    Pipe<WAVES, pinned_walk<Mode, NT>()> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
-#ifdef NRF_YOUNG_PRIO
-    if (WAVES == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // the second-dispatched half loses VALU arbitration otherwise (MI355X_MICROARCH, two waves per SIMD, item 4)
-#endif
 
     const RenderArgs& a = P.a;
     const int S = a.n_samples;
     const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, a.z_ladder);
-    // Samples per ray and MLP pass (host: pick_spw_log2).  The wave's 32 sample columns are RPW = 32/SPW rays x SPW consecutive
-    // samples: column c = ray (c mod RPW), sample (pass*SPW + c div RPW).  A ray is still composited front to back by ONE lane
-    // (column c < RPW of the low lane half), which fetches the other columns' network outputs with ds_bpermute -- the per-ray
-    // sequence of operations, hence every bit of the result, does not depend on SPW.  What SPW buys: frames whose ray count
-    // does not fill whole rounds of 256-ray tiles over the CUs (400x400; an 80 000-ray shard) are cut into 2x / 4x as many,
-    // shorter, work items.
+    // Samples per ray and MLP pass (host: pick_spw_log2).  The wave's COLS sample columns are RPW = COLS/SPW rays x SPW consecutive
+    // samples: column q = ray (q mod RPW), sample (pass*SPW + q div RPW).  A ray is still composited front to back by ONE lane
+    // (lane L < RPW owns ray L of the wave; its state rows are the ones of thread L), which fetches the other columns' network
+    // outputs with ds_bpermute -- the per-ray sequence of operations, hence every bit of the result, depends neither on SPW nor
+    // on NT.  The state rows of a lane >= RPW mirror ray (lane mod RPW): column q's origin / direction are read from thread q's rows.
+    // What SPW buys: frames whose ray count does not fill whole rounds of 256-ray tiles over the CUs (400x400; an 80 000-ray
+    // shard) are cut into 2x / 4x as many, shorter, work items.
     const int spw_log2 = a.spw_log2;
-    const int SPW = 1 << spw_log2, RPW = 32 >> spw_log2;
+    const int rpw_log2 = (NT == 2 ? 6 : 5) - spw_log2;
+    const int SPW = 1 << spw_log2, RPW = COLS >> spw_log2;
     const int64_t tile_rays = (int64_t)WAVES * RPW;
     const int n_pass = (S + SPW - 1) >> spw_log2;
 
@@ -141,13 +141,13 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     };
 
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
-        // this column's ray (clamped: the columns past the last ray of a ragged tile repeat it and store nothing)
-        auto column_ray = [&]() -> int64_t {
-            const int64_t r = tile * tile_rays + wave * RPW + (c & (RPW - 1));
+        // column q's ray (clamped: the columns past the last ray of a ragged tile repeat it and store nothing)
+        auto column_ray = [&](int q) -> int64_t {
+            const int64_t r = tile * tile_rays + wave * RPW + (q & (RPW - 1));
             return r < a.n_rays ? r : a.n_rays - 1;
         };
         {
-            const int64_t rid = column_ray();
+            const int64_t rid = column_ray(lane);
             float o[3], d[3];
             if (a.camera_mode) {
                 int ci;
@@ -170,38 +170,47 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             lane = tid_now & 63; c = lane & 31; h = lane >> 5;
             st_me = st + tid_now;
 
+            // the state rows of column q = c + 32 n of this wave (NT == 1: the lane's own -- both lane halves mirror the ray)
+            auto SQ = [&](int n, int f) -> NRF_LDS float& { return (NT == 1 ? st_me : st_me - lane + c + 32 * n)[f * nthreads]; };
             // view direction = raw rays_d (train.py:225); encoded on demand inside the network walk
             auto dirT = [&](Act (&dt)[1][NT]) {
-                const float d[3] = {ST(F_DX), ST(F_DY), ST(F_DZ)};
-                Act t1[pe_tiles(LD)];
-                encode3<Mode, LD>(d, h, t1);
-                dt[0][0] = t1[0];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const float d[3] = {SQ(n, F_DX), SQ(n, F_DY), SQ(n, F_DZ)};
+                    Act t1[pe_tiles(LD)];
+                    encode3<Mode, LD>(d, h, t1);
+                    dt[0][n] = t1[0];
+                }
             };
             // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
             auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
-                // depth of this column's sample (columns past the last sample repeat it; their outputs are not used)
-                float zc;
-                if (SPW == 1) {
-                    zc = ST(F_Z);
-                } else {
-                    const int sc = p * SPW + (c >> (5 - spw_log2));
-                    zc = z_ray(column_ray(), sc < S ? sc : S - 1);
-                }
-                float pt[3];
-                pt[0] = point_on_ray(ST(F_OX), ST(F_DX), zc);
-                pt[1] = point_on_ray(ST(F_OY), ST(F_DY), zc);
-                pt[2] = point_on_ray(ST(F_OZ), ST(F_DZ), zc);
-                Act e1[KT0];
-                encode3<Mode, LP>(pt, h, e1, w0[0]);
 #pragma unroll
-                for (int t = 0; t < KT0; ++t) x[t][0] = e1[t];
-                if constexpr (Net::kDino) {
-                    constexpr int DT = Net::KT0 - KT0;
-                    const DinoTaps tp = dino_taps(a.dino, pt);
-                    Act dt[DT];
-                    dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[0], dt);
+                for (int n = 0; n < NT; ++n) {
+                    // depth of this column's sample (columns past the last sample repeat it; their outputs are not used)
+                    float zc;
+                    if (SPW == 1) {
+                        zc = SQ(n, F_Z);
+                    } else {
+                        const int q = c + 32 * n;
+                        const int sc = p * SPW + (q >> rpw_log2);
+                        zc = z_ray(column_ray(q), sc < S ? sc : S - 1);
+                    }
+                    float pt[3];
+                    pt[0] = point_on_ray(SQ(n, F_OX), SQ(n, F_DX), zc);
+                    pt[1] = point_on_ray(SQ(n, F_OY), SQ(n, F_DY), zc);
+                    pt[2] = point_on_ray(SQ(n, F_OZ), SQ(n, F_DZ), zc);
+                    Act e1[KT0];
+                    encode3<Mode, LP>(pt, h, e1, w0[n]);
 #pragma unroll
-                    for (int t = 0; t < DT; ++t) x[KT0 + t][0] = dt[t];
+                    for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
+                    if constexpr (Net::kDino) {
+                        constexpr int DT = Net::KT0 - KT0;
+                        const DinoTaps tp = dino_taps(a.dino, pt);
+                        Act dt[DT];
+                        dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
+#pragma unroll
+                        for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
+                    }
                 }
             };
 
@@ -209,9 +218,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
 
             // ---- composite this pass's SPW samples of the lane's ray, front to back --------------------------------------
-            const int64_t rid = column_ray();
-            const int64_t raw = tile * tile_rays + wave * RPW + (c & (RPW - 1));
-            const bool own_valid = h == 0 && c < RPW && raw < a.n_rays;
+            const int64_t rid = column_ray(lane);
+            const int64_t raw = tile * tile_rays + wave * RPW + (lane & (RPW - 1));
+            const bool own_valid = lane < RPW && raw < a.n_rays;
             Composite comp;
             comp.T = ST(F_T); comp.r = ST(F_R); comp.g = ST(F_G); comp.b = ST(F_B); comp.depth = ST(F_DEPTH); comp.acc = ST(F_ACC);
             float zo = ST(F_Z);
@@ -221,15 +230,22 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                 if (s >= S) break;
                 const bool last = (s + 1 == S);
                 float v[4];
-                if (j == 0) {
+                if (SPW == 1) {
+                    // NT == 2: lane L owns column L = tile h, column c -- and holds that tile's head rows itself
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = (NT == 2 && h) ? out4[NT - 1][k] : out4[0][k];
+                } else if (j == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = out4[0][k];
                 } else {
-                    // the outputs of sample s of this lane's ray sit in column c + j*RPW of the same lane half
-                    const int src = (lane + j * RPW) << 2;
+                    // the outputs of sample s of this lane's ray sit in column q = lane + j*RPW: tile q div 32 (the same for every
+                    // owner lane), lane q mod 32 of the same lane half
+                    const int qj = lane + (j << rpw_log2);
+                    const bool upper = NT == 2 && ((j << rpw_log2) & 32);
+                    const int src = ((lane & 32) | (qj & 31)) << 2;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, out4[0][k])));
+                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, upper ? out4[NT - 1][k] : out4[0][k])));
                 }
                 const float zn = last ? 0.0f : z_ray(rid, s + 1);
                 const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zo), norm);
@@ -246,8 +262,8 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
         }
 
         {
-            const int64_t raw = tile * tile_rays + wave * RPW + (c & (RPW - 1));
-            if (h == 0 && c < RPW && raw < a.n_rays) {
+            const int64_t raw = tile * tile_rays + wave * RPW + (lane & (RPW - 1));
+            if (lane < RPW && raw < a.n_rays) {
                 float r = ST(F_R), g = ST(F_G), b = ST(F_B);
                 if (a.white_bkgd) {                                      // nerf_mlp.py:209-212
                     const float bg = __fsub_rn(1.0f, ST(F_ACC));
@@ -270,18 +286,20 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 // ---------------------------------------------------------------------------------------------
 // fused renderer with per-ray early termination: persistent lanes fed from a ray queue
 // ---------------------------------------------------------------------------------------------
-// When ert_eps > 0 the marching is no longer tile-synchronous.  Every lane pair (c, c+32) holds ONE ray and its own
+// When ert_eps > 0 the marching is no longer tile-synchronous.  Every sample column of a wave holds ONE ray and its own
 // sample index; each MLP pass advances every live ray by one sample; a ray that has used its S samples or whose
-// transmittance fell below ert_eps is written out and its lane pair takes the next ray of the wave's strip.  Strips
-// (kStrip consecutive ray ids) come from one device-wide atomic counter, so workgroups drain the frame together.
-// Both lanes of a pair run the identical compositor (the head tile carries [r,g,b,sigma] for both halves), so they
-// agree on termination without exchanging anything; only the low lane stores.  Per-ray arithmetic is exactly that of
+// transmittance fell below ert_eps is written out and its column takes the next ray of the wave's strip.  Strips
+// (kStrip * NT consecutive ray ids) come from one device-wide atomic counter, so workgroups drain the frame together.
+// NT == 1 (32 columns): both lanes of a pair (c, c+32) hold the column's ray and run the identical compositor (the head tile
+// carries [r,g,b,sigma] for both halves), so they agree on termination without exchanging anything; only the low lane stores.
+// NT == 2 (64 columns): lane L owns column L = operand tile L div 32, column L mod 32.  Per-ray arithmetic is exactly that of
 // render_kernel, so with ert_eps -> 0 the image is the same; with ert_eps > 0 each ray stops at ITS OWN T < eps.
-constexpr int kStrip = 32;        // rays handed out per atomic: one wave-load, so that the frame's last strips spread over all waves (128 left a 4-batch tail: +18 %)
+constexpr int kStrip = 32;        // rays handed out per atomic and 32 columns: one wave-load, so that the frame's last strips spread over all waves (4 wave-loads left a 4-batch tail: +18 %)
 
-template <class Net, class Mode, int WAVES, int LP, int LD>
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKArgs P) {
-    constexpr int NT = 1;
+    static_assert(NT == 1 || NT == 2, "a wave marches 32 or 64 sample columns");
+    constexpr int STRIP = kStrip * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NRF_LDS char* lds = (NRF_LDS char*)smem;
     NRF_LDS float* bias = (NRF_LDS float*)(lds + kLdsRing);
@@ -314,7 +332,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     ST(F_OX) = 0.f; ST(F_OY) = 0.f; ST(F_OZ) = 0.f; ST(F_DX) = 0.f; ST(F_DY) = 0.f; ST(F_DZ) = -1.f; ST(F_Z) = 1.f;
     load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
 
-    Pipe<WAVES, false, Mode::kPinned> pipe;     // a wave that has run dry keeps computing (on stale inputs, storing nothing): the workgroup moves in lockstep anyway, and the skip paths cost registers in every layer
+    Pipe<WAVES, pinned_walk<Mode, NT>()> pipe;     // a wave that has run dry keeps computing (on stale inputs, storing nothing): the workgroup moves in lockstep anyway, and the skip paths cost registers in every layer
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
@@ -337,7 +355,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
         return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));
     };
 
-    // registers: only the ray id and its sample index (identical in both lanes of a pair)
+    // registers: only the ray id and its sample index (NT == 1: identical in both lanes of a pair)
     int ray = -1;
     int s = 0;
     // wave-uniform queue state
@@ -352,23 +370,23 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
         // ---- hand new rays to idle lane pairs -------------------------------------------------
         if (!pipe.skip) {
             const bool need = ray < 0;
-            const uint32_t m = (uint32_t)(__ballot(need) & 0xFFFFFFFFull);          // pairs are identical: low half suffices
-            const int cnt = __builtin_popcount(m);
+            const uint64_t m = NT == 2 ? (uint64_t)__ballot(need) : (uint64_t)(__ballot(need) & 0xFFFFFFFFull);   // NT == 1: pairs are identical, the low half suffices
+            const int cnt = __builtin_popcountll(m);
             if (cnt > 0 && !exhausted) {
                 if (pool_next == pool_end) {
                     unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(a.queue, (unsigned long long)kStrip);
+                    if (lane == 0) base = atomicAdd(a.queue, (unsigned long long)STRIP);
                     base = ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(base >> 32)) << 32) |
                            (unsigned)__builtin_amdgcn_readfirstlane((unsigned)base);
                     if ((int64_t)base >= a.n_rays) {
                         exhausted = true;
                     } else {
                         pool_next = (int64_t)base;
-                        pool_end = (int64_t)base + kStrip < a.n_rays ? (int64_t)base + kStrip : a.n_rays;
+                        pool_end = (int64_t)base + STRIP < a.n_rays ? (int64_t)base + STRIP : a.n_rays;
                     }
                 }
                 if (pool_next < pool_end) {
-                    const int64_t idx = pool_next + __builtin_popcount(m & ((1u << c) - 1u));
+                    const int64_t idx = pool_next + __builtin_popcountll(m & ((1ull << (NT == 2 ? lane : c)) - 1ull));
                     if (need && idx < pool_end) {
                         ray = (int)idx;
                         s = 0;
@@ -396,30 +414,38 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
         }
 
         // ---- one sample per live ray ----------------------------------------------------------
+        // the state rows of column q = c + 32 n of this wave (NT == 1: the lane's own)
+        auto SQ = [&](int n, int f) -> NRF_LDS float& { return (NT == 1 ? st_me : st_me - lane + c + 32 * n)[f * nthreads]; };
         auto dirT = [&](Act (&dt)[1][NT]) {
-            const float d[3] = {ST(F_DX), ST(F_DY), ST(F_DZ)};
-            Act t1[pe_tiles(LD)];
-            encode3<Mode, LD>(d, h, t1);
-            dt[0][0] = t1[0];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const float d[3] = {SQ(n, F_DX), SQ(n, F_DY), SQ(n, F_DZ)};
+                Act t1[pe_tiles(LD)];
+                encode3<Mode, LD>(d, h, t1);
+                dt[0][n] = t1[0];
+            }
         };
         auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
             if (pipe.skip) return;
-            const float zc = ST(F_Z);
-            float p[3];
-            p[0] = point_on_ray(ST(F_OX), ST(F_DX), zc);
-            p[1] = point_on_ray(ST(F_OY), ST(F_DY), zc);
-            p[2] = point_on_ray(ST(F_OZ), ST(F_DZ), zc);
-            Act e1[KT0];
-            encode3<Mode, LP>(p, h, e1, w0[0]);
 #pragma unroll
-            for (int t = 0; t < KT0; ++t) x[t][0] = e1[t];
-            if constexpr (Net::kDino) {
-                constexpr int DT = Net::KT0 - KT0;
-                const DinoTaps tp = dino_taps(a.dino, p);
-                Act dt[DT];
-                dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[0], dt);
+            for (int n = 0; n < NT; ++n) {
+                const float zc = SQ(n, F_Z);
+                float p[3];
+                p[0] = point_on_ray(SQ(n, F_OX), SQ(n, F_DX), zc);
+                p[1] = point_on_ray(SQ(n, F_OY), SQ(n, F_DY), zc);
+                p[2] = point_on_ray(SQ(n, F_OZ), SQ(n, F_DZ), zc);
+                Act e1[KT0];
+                encode3<Mode, LP>(p, h, e1, w0[n]);
 #pragma unroll
-                for (int t = 0; t < DT; ++t) x[KT0 + t][0] = dt[t];
+                for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
+                if constexpr (Net::kDino) {
+                    constexpr int DT = Net::KT0 - KT0;
+                    const DinoTaps tp = dino_taps(a.dino, p);
+                    Act dt[DT];
+                    dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
+                }
             }
         };
         float out4[NT][4];
@@ -433,16 +459,20 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
             const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
             Composite comp;
             comp.T = ST(F_T); comp.r = ST(F_R); comp.g = ST(F_G); comp.b = ST(F_B); comp.depth = ST(F_DEPTH); comp.acc = ST(F_ACC);
-            const float w = comp.template add<Mode::FAST_EXP>(out4[0][3], sigmoid_sel<Mode::FAST_EXP>(out4[0][0]),
-                                                              sigmoid_sel<Mode::FAST_EXP>(out4[0][1]), sigmoid_sel<Mode::FAST_EXP>(out4[0][2]), zc, dist);
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (NT == 2 && h) ? out4[NT - 1][k] : out4[0][k];
+            const float w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]),
+                                                              sigmoid_sel<Mode::FAST_EXP>(v[1]), sigmoid_sel<Mode::FAST_EXP>(v[2]), zc, dist);
             const int64_t rr = ray;
-            if (h == 0) {
+            const bool stores = NT == 2 || h == 0;
+            if (stores) {
                 if (a.weights) a.weights[rr * S + s] = w;
                 if (a.z_vals) a.z_vals[rr * S + s] = zc;
             }
             const bool fin = last || comp.T < a.ert_eps;
             if (fin) {
-                if (h == 0) {
+                if (stores) {
                     // samples skipped by early termination carry weight < ert_eps: report 0 and their depths
                     for (int s2 = s + 1; s2 < S; ++s2) {
                         if (a.weights) a.weights[rr * S + s2] = 0.0f;
@@ -501,7 +531,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
     const int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     load_bias_table(bias, P.net.bias, P.net.n_bias);
-    Pipe<WAVES, false, Mode::kPinned> pipe;
+    Pipe<WAVES, pinned_walk<Mode, NT>()> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
     const int own = (NT == 2) ? h : 0;
@@ -632,17 +662,17 @@ inline int pick_spw_log2(int64_t n_rays, int S, int waves, int cu) {
     return best;
 }
 
-template <class Net, class Mode, int WAVES, int LP, int LD>
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
-    auto kernel = render_kernel<Net, Mode, WAVES, LP, LD>;
+    auto kernel = render_kernel<Net, Mode, NT, WAVES, LP, LD>;
     static unsigned char done[64] = {};
     const int prepared = prepare(kernel, net.device, done, err, kLdsBytesQueue);
     if (prepared != NRF_OK) return prepared;
     RenderKArgs k;
     k.net = net_args(net, mode);
     k.a = a;
-    k.a.spw_log2 = pick_spw_log2(a.n_rays, a.n_samples, WAVES, net.cu_count);
-    const int64_t tile = (int64_t)WAVES * (32 >> k.a.spw_log2);
+    k.a.spw_log2 = pick_spw_log2(a.n_rays, a.n_samples, WAVES * NT, net.cu_count);
+    const int64_t tile = (int64_t)WAVES * ((32 * NT) >> k.a.spw_log2);
     k.n_tiles = (a.n_rays + tile - 1) / tile;
     const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytesQueue, s, k);
@@ -651,9 +681,9 @@ int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_
     return NRF_OK;
 }
 
-template <class Net, class Mode, int WAVES, int LP, int LD>
+template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_render_queue(const DeviceNet& net, int mode, RenderArgs a, hipStream_t s, std::string& err) {
-    auto kernel = render_queue_kernel<Net, Mode, WAVES, LP, LD>;
+    auto kernel = render_queue_kernel<Net, Mode, NT, WAVES, LP, LD>;
     static unsigned char done[64] = {};
     const int prepared = prepare(kernel, net.device, done, err, kLdsBytesQueue);
     if (prepared != NRF_OK) return prepared;
@@ -665,7 +695,7 @@ int run_render_queue(const DeviceNet& net, int mode, RenderArgs a, hipStream_t s
     k.net = net_args(net, mode);
     k.a = a;
     k.n_tiles = 0;
-    const int64_t strips = (a.n_rays + kStrip - 1) / kStrip;
+    const int64_t strips = (a.n_rays + kStrip * NT - 1) / (kStrip * NT);
     const int64_t blocks = (strips + WAVES - 1) / WAVES;
     const int64_t grid = blocks < net.cu_count ? blocks : net.cu_count;
     hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(WAVES * 64), kLdsBytesQueue, s, k);
@@ -676,13 +706,12 @@ int run_render_queue(const DeviceNet& net, int mode, RenderArgs a, hipStream_t s
 
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
 int run_render(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {
-    static_assert(NT == 1, "the renderers march one sample tile per wave");
     if (a.ert_eps > 0.0f) {
         // per-ray early termination: the ray-queue kernel (one ray per lane pair, refilled from a device-wide queue)
         if (!net.queues || a.n_rays >= (int64_t)1 << 31) { err = "early ray termination: launch too large (>= 2^31 rays)"; return NRF_EINVAL; }
-        return run_render_queue<Net, Mode, WAVES, LP, LD>(net, mode, a, s, err);
+        return run_render_queue<Net, Mode, NT, WAVES, LP, LD>(net, mode, a, s, err);
     }
-    return run_render_v<Net, Mode, WAVES, LP, LD>(net, mode, a, s, err);
+    return run_render_v<Net, Mode, NT, WAVES, LP, LD>(net, mode, a, s, err);
 }
 
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
@@ -710,28 +739,34 @@ bool check_net(const DeviceNet& net, int mode, std::string& err) {
 
 }  // namespace
 
-// Workgroup geometry per arithmetic mode: the 16-bit modes run 8 waves x 32 samples (two waves per SIMD, <= 256 registers, each
-// covering the other's epilogue / waits); the fp32 and split-f16 modes 4 waves x 32 samples (their activations take 16 registers
-// per tile: one wave per SIMD with the whole 512-register file).
+// Workgroup geometry per arithmetic mode and network family (NT sample tiles per wave, WAVES).  Every geometry marches 256
+// sample columns per workgroup and weight pass.
+//   * 16-bit modes, V1 / V2: 4 waves x 64 columns, one wave per SIMD on the whole 512-entry register file, pinned walk.  A fragment
+//     read from LDS feeds two MFMAs (half the LDS bytes per FLOP), and nothing spills (the 8 x 32 build of V2 carried 40-50
+//     spilled registers): V2 +8 %, V1 +1...2 % over 8 x 32 on the same box (profiles/r02_ab_wide16.txt).
+//   * 16-bit modes, V3: 8 waves x 32 columns, two per SIMD, hipcc's schedule: its per-pass feature-map gather (global loads, twice
+//     per pass) is latency one wave per SIMD cannot cover (4 x 64: -3...5 %).
+//   * fp32 and split-f16: 4 waves x 32 columns (their activations take 16 registers per tile).
+// The images are bit-identical across geometries (tools/image_hash.py): a column's arithmetic does not depend on where it sits.
 #define NRF_DISPATCH_MODE(FN, NET, LP, ...)                                                                 \
     switch (mode) {                                                                                         \
-        case NRF_MMA_BF16: return FN<NET<ModeBF16, 1, LP>, ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);             \
-        case NRF_MMA_F16:  return FN<NET<ModeF16, 1, LP>, ModeF16, 1, 8, LP, 4>(__VA_ARGS__);               \
+        case NRF_MMA_BF16: return FN<NET<ModeBF16, 2, LP>, ModeBF16, 2, 4, LP, 4>(__VA_ARGS__);             \
+        case NRF_MMA_F16:  return FN<NET<ModeF16, 2, LP>, ModeF16, 2, 4, LP, 4>(__VA_ARGS__);               \
         case NRF_MMA_F16X3: return FN<NET<ModeF16X3, 1, LP>, ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);         \
         default: return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                         \
     }
 
-// V2 / V3: one geometry per mode (8 waves x 32 samples for the 16-bit modes, 4 x 32 for fp32)
-#define NRF_DISPATCH_MODE1(FN, NETT, LP, ...)                                                               \
+// V2 / V3 (NT16, WAVES16: the 16-bit modes' geometry)
+#define NRF_DISPATCH_MODE1(FN, NETT, LP, NT16, WAVES16, ...)                                                \
     switch (mode) {                                                                                         \
-        case NRF_MMA_BF16: return FN<NETT(ModeBF16), ModeBF16, 1, 8, LP, 4>(__VA_ARGS__);                   \
-        case NRF_MMA_F16:  return FN<NETT(ModeF16), ModeF16, 1, 8, LP, 4>(__VA_ARGS__);                     \
-        case NRF_MMA_F16X3: return FN<NETT(ModeF16X3), ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);              \
-        default:           return FN<NETT(ModeF32), ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                     \
+        case NRF_MMA_BF16: return FN<NETT(ModeBF16, NT16), ModeBF16, NT16, WAVES16, LP, 4>(__VA_ARGS__);    \
+        case NRF_MMA_F16:  return FN<NETT(ModeF16, NT16), ModeF16, NT16, WAVES16, LP, 4>(__VA_ARGS__);      \
+        case NRF_MMA_F16X3: return FN<NETT(ModeF16X3, 1), ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);           \
+        default:           return FN<NETT(ModeF32, 1), ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                  \
     }
-#define NRF_NET_V2_10(M) NetV2<M, 1, 10>
-#define NRF_NET_V3_12_64(M) NetV3<M, 1, 12, 2>
-#define NRF_NET_V3_12_128(M) NetV3<M, 1, 12, 4>
+#define NRF_NET_V2_10(M, NT) NetV2<M, NT, 10>
+#define NRF_NET_V3_12_64(M, NT) NetV3<M, NT, 12, 2>
+#define NRF_NET_V3_12_128(M, NT) NetV3<M, NT, 12, 4>
 
 // per-family entry points, one translation unit each (fused_v1.hip ... fused_v3w.hip) so that hipcc builds them in parallel
 int render_v1(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);

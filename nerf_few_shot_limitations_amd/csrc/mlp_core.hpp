@@ -1,8 +1,9 @@
 // mlp_core.hpp -- the MFMA machinery of the fused NeRF MLP (gfx950 only).
 //
 // Geometry (DESIGN.md "MLP kernel"):
-//   * one workgroup = 4 waves = one CU; a wave owns 32*NT samples; features sit
-//     on the MFMA ROW axis, samples on the LANE (column) axis:
+//   * one workgroup = one CU = 256 sample columns per weight pass: WAVES waves x NT tiles of 32 columns (8 x 1: two waves per
+//     SIMD; 4 x 2 or 4 x 1: one wave per SIMD -- fused_impl.hpp, "Workgroup geometry"); features sit on the MFMA ROW axis,
+//     samples on the LANE (column) axis:
 //          H_next[feature][sample] = W[feature][k] * H[k][sample]
 //     so a layer's 32x32 fp32 accumulator tile (column on the lane, rows in its
 //     16 registers) is, after ReLU + down-conversion, directly the B operand of
@@ -10,9 +11,9 @@
 //   * the weights (A operand) are pre-packed on the host into 1-KiB "fragments"
 //     (64 lanes x 16 B, exactly one ds_read_b128 per lane) in the order the
 //     kernel consumes them and streamed L2 -> LDS with global_load_lds into a
-//     ring of NSLOT 16-KiB chunks, NSLOT-1 chunks ahead of the MFMAs; all four
-//     waves share every fragment; one raw s_barrier per chunk (32*NT MFMAs per
-//     wave) with a counted vmcnt keeps the prefetch in flight across it.
+//     ring of NSLOT 16-KiB chunks, NSLOT-2 chunks ahead of the MFMAs; all
+//     waves share every fragment (a wave feeds it to NT MFMAs); one raw s_barrier per chunk
+//     (16*NT MFMAs per wave) with a counted vmcnt keeps the prefetch in flight across it.
 //
 // K order inside a fragment (cdna_hip_programming.md section 3, "An accumulator
 // tile as the next MFMA's operand"): for lane (i = lane&31, h = lane>>5)
@@ -83,9 +84,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // first fragments of chunk X are already in flight while the last MFMAs of chunk X-1 run: that is why the
 // slot recycled at the barrier is the one two chunks back, not one.
 // ASM_DMA: issue the LDS-DMA as inline asm (the one-wave-per-SIMD modes: see dense_pinned()).
-template <int WAVES, bool CAN_SKIP = false, bool ASM_DMA = false>
+template <int WAVES, bool ASM_DMA = false>
 struct Pipe {
-    static constexpr bool kCanSkip = CAN_SKIP;    // early-ray-termination build: a wave may sit out the math (see dense())
     static constexpr int kFragsPerWave = kChunkFrags / WAVES;    // glds instructions per wave per chunk
     static constexpr int kAhead = kSlots - 2;                    // chunks in flight / landed ahead of the reader
     const NRF_GLB char* src;   // packed stream + wave*kFragsPerWave KiB + lane*16
@@ -98,7 +98,7 @@ struct Pipe {
     uint32_t wave_off;         // wave * kFragsPerWave KiB (wave-uniform)
     uint32_t lane_off;         // lane * 16
     uint32_t ablate;           // timing experiments only (NRF_ABLATE): 1 = stop streaming after the first fill, 2 = no barriers
-    uint32_t skip;             // wave-uniform: this wave's rays are all terminated -> keep the stream protocol, skip the math
+    uint32_t skip;             // wave-uniform flag of the ray-queue kernel: this wave has run dry (it keeps computing, stores nothing)
 
     __device__ __forceinline__ void init(const void* stream, uint32_t chunks, NRF_LDS char* ring_base, uint32_t ablate_flags = 0) {
         ablate = ablate_flags;
@@ -156,7 +156,7 @@ struct Pipe {
 // ---------------------------------------------------------------------------
 struct ModeBF16 {
     static constexpr int SUB = 2;            // fragments per (m-tile, k-tile)
-    static constexpr bool kPinned = false;   // two waves per SIMD cover each other: hipcc's own schedule is the faster one
+    static constexpr bool kPinned = false;   // at two waves per SIMD (NT = 1) the waves cover each other: hipcc's own schedule is as fast (pinned: +0.5 %)
     static constexpr int TRIG = 1;           // v_sin on exactly reduced turns: error far below bf16 resolution (nets.hpp:encode3)
     static constexpr bool FAST_EXP = true;   // v_exp based exp/sigmoid in the compositor
     typedef bf16x8 frag_t;
@@ -175,6 +175,14 @@ struct ModeBF16 {
             o.f[s] = __builtin_bit_cast(bf16x8, w);
         }
         return o;
+    }
+    template <bool RELU>
+    __device__ static __forceinline__ void to_act_pair(const f32x16& v, int j, Act& o) {     // dense_pinned's epilogue slice
+        int nw = pack_pair<bf16x2, RELU>(v[2 * j], v[2 * j + 1]);
+        asm volatile("" : "+v"(nw));
+        i32x4 w = __builtin_bit_cast(i32x4, o.f[j >> 2]);
+        w[j & 3] = nw;
+        o.f[j >> 2] = __builtin_bit_cast(bf16x8, w);
     }
 };
 
@@ -199,6 +207,14 @@ struct ModeF16 {
             o.f[s] = __builtin_bit_cast(f16x8, w);
         }
         return o;
+    }
+    template <bool RELU>
+    __device__ static __forceinline__ void to_act_pair(const f32x16& v, int j, Act& o) {     // dense_pinned's epilogue slice
+        int nw = pack_pair<f16x2, RELU>(v[2 * j], v[2 * j + 1]);
+        asm volatile("" : "+v"(nw));
+        i32x4 w = __builtin_bit_cast(i32x4, o.f[j >> 2]);
+        w[j & 3] = nw;
+        o.f[j >> 2] = __builtin_bit_cast(f16x8, w);
     }
 };
 
@@ -310,6 +326,12 @@ __device__ __forceinline__ void load_bias(f32x16& acc, const NRF_LDS float* bias
 // the read stream never stops inside a layer.
 constexpr __host__ __device__ int chunks_for_frags(int frags) { return (frags + kChunkFrags - 1) / kChunkFrags; }
 
+// Which layer walk a geometry uses: one wave per SIMD -- the fp32-class split mode, and any mode at NT = 2 sample tiles per wave
+// (64 columns: 128 + 128 operand registers and 64 accumulators, i.e. the whole 512-entry file) -- takes dense_pinned() and issues
+// its LDS-DMA as inline asm; two waves per SIMD (16-bit modes at NT = 1) and the fp32 MFMA mode take dense().
+template <class Mode, int NT>
+constexpr __host__ __device__ bool pinned_walk() { return Mode::kPinned || NT > 1; }
+
 #ifndef NRF_PREFETCH
 #define NRF_PREFETCH 3
 #endif
@@ -327,13 +349,6 @@ __device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,
     constexpr int PF = NF < kPrefetch ? NF : kPrefetch;
     constexpr int EPI = PER_M > kEpilogueAt ? kEpilogueAt : PER_M - 1;
     typedef typename Mode::frag_t frag_t;
-    if constexpr (P::kCanSkip) if (pipe.skip) {
-        // early ray termination, wave level: all 32*NT rays of this wave are opaque.  The wave still takes part in
-        // every chunk hand-over (its share of the LDS-DMA, the barriers) but issues no LDS reads, MFMAs or epilogues.
-#pragma unroll
-        for (int c = 0; c < chunks_for_frags(NF); ++c) pipe.acquire(c & 1);
-        return;
-    }
     frag_t fr[PF];
     auto read = [&](auto g_) -> frag_t {
         constexpr int g = decltype(g_)::value;
@@ -367,7 +382,7 @@ __device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,
     fin(std::integral_constant<int, MT - 1>{}, acc[(MT - 1) & 1]);
 }
 
-// The same layer for the modes that run ONE wave per SIMD (Mode::kPinned).  There nothing covers what the wave itself does not
+// The same layer for the geometries that run ONE wave per SIMD (pinned_walk<Mode, NT>()).  There nothing covers what the wave itself does not
 // overlap, and hipcc's schedule does two things that cost a quarter of the MFMA pipe: it sinks every fragment read to just in
 // front of its MFMA, and it gathers the epilogues of several tiles into single blocks of ~280 VALU instructions between two
 // MFMAs.  Here every fragment step is fenced (__builtin_amdgcn_sched_barrier): step f = the MFMAs of fragment f, the read of
@@ -428,7 +443,7 @@ __device__ __forceinline__ void dense_pinned(P& pipe, const NRF_LDS float* bias,
 template <class Mode, int KT, int MT, int NT, bool RELU, class P>
 __device__ __forceinline__ void dense_act(P& pipe, const NRF_LDS float* bias, int h,
                                           const typename Mode::Act (&in)[KT][NT], typename Mode::Act (&out)[MT][NT]) {
-    if constexpr (Mode::kPinned) {
+    if constexpr (pinned_walk<Mode, NT>()) {
         dense_pinned<Mode, KT, MT, NT>(pipe, bias, h, in, [&](auto m_, f32x16(&acc)[NT], auto j_) {
             constexpr int m = decltype(m_)::value;
 #pragma unroll
@@ -447,7 +462,7 @@ __device__ __forceinline__ void dense_act(P& pipe, const NRF_LDS float* bias, in
 template <class Mode, int KT, int NT, class P>
 __device__ __forceinline__ void dense_head(P& pipe, const NRF_LDS float* bias, int h,
                                            const typename Mode::Act (&in)[KT][NT], f32x16 (&out)[NT]) {
-    if constexpr (Mode::kPinned) {
+    if constexpr (pinned_walk<Mode, NT>()) {
         dense_pinned<Mode, KT, 1, NT>(pipe, bias, h, in, [&](auto, f32x16(&acc)[NT], auto j_) {
             constexpr int j = decltype(j_)::value;
 #pragma unroll

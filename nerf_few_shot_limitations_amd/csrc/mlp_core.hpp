@@ -97,7 +97,7 @@ struct Pipe {
     uint32_t read_slot;
     uint32_t wave_off;         // wave * kFragsPerWave KiB (wave-uniform)
     uint32_t lane_off;         // lane * 16
-    uint32_t ablate;           // timing experiments only (NRF_ABLATE): 1 = stop streaming after the first fill, 2 = no barriers
+    uint32_t ablate;           // timing experiments only (builds with -DNRF_ABLATE_BUILD, env NRF_ABLATE): 1 = stop streaming after the first fill, 2 = no barriers
     uint32_t skip;             // wave-uniform flag of the ray-queue kernel: this wave has run dry (it keeps computing, stores nothing)
 
     __device__ __forceinline__ void init(const void* stream, uint32_t chunks, NRF_LDS char* ring_base, uint32_t ablate_flags = 0) {
@@ -112,24 +112,33 @@ struct Pipe {
         issue_chunk = 0; issue_slot = 0; read_slot = 0;
         base[0] = base[1] = ring_base + lane_off;
     }
+    // One chunk: this wave's kFragsPerWave consecutive fragments.  ONE address pair and ONE LDS base (M0) serve all of them: the
+    // instruction's immediate offset moves the global and the LDS address alike.  (Per-fragment address arithmetic and M0 traffic
+    // made this ~45 scalar / vector instructions per chunk; at one wave per SIMD that was a ~120-cycle hole in the MFMA stream
+    // behind every chunk barrier.)
     __device__ __forceinline__ void issue_one() {
         const NRF_GLB char* g = src + (size_t)issue_chunk * kChunkBytes;
         NRF_LDS char* l = ring + issue_slot * kChunkBytes + wave_off;
-#pragma unroll
-        for (int i = 0; i < kFragsPerWave; ++i) {
-            if constexpr (ASM_DMA) {
-                // hipcc then tracks neither the DMA's vmcnt (waited for by hand in acquire()) nor -- the point -- an LDS access
-                // through a FLAT-encoded instruction, whose "pending flat" state makes its waitcnt pass answer the fragment reads
-                // that follow with lgkmcnt(0) instead of counted waits.  M0 (the DMA's LDS base) is saved and restored inside the
-                // statement.  (Measured: +1 % for the split-f16 kernel, -3 % for the two-waves-per-SIMD 16-bit kernels.)
-                const NRF_GLB char* gp = g + i * kFragBytes;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(l + i * kFragBytes));
-                uint32_t keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(gp), "s"(dst) : "memory");
-            } else {
-                __builtin_amdgcn_global_load_lds((const NRF_GLB void*)(g + i * kFragBytes), (NRF_LDS void*)(l + i * kFragBytes), 16, 0, 0);
-            }
+        if constexpr (ASM_DMA) {
+            // hipcc then tracks neither the DMA's vmcnt (waited for by hand in acquire()) nor -- the point -- an LDS access
+            // through a FLAT-encoded instruction, whose "pending flat" state makes its waitcnt pass answer the fragment reads
+            // that follow with lgkmcnt(0) instead of counted waits.
+            static_assert(kFragsPerWave == 2 || kFragsPerWave == 4, "LDS-DMA asm written for 2 or 4 fragments per wave and chunk");
+            const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)l);
+            if constexpr (kFragsPerWave == 4)
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024\n\t"
+                             "global_load_lds_dwordx4 %0, off offset:2048\n\tglobal_load_lds_dwordx4 %0, off offset:3072"
+                             : : "v"(g), "s"(dst) : "memory", "m0");
+            else
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %0, off\n\tglobal_load_lds_dwordx4 %0, off offset:1024"
+                             : : "v"(g), "s"(dst) : "memory", "m0");
+        } else {
+            static_for<kFragsPerWave>([&](auto i_) {
+                constexpr int i = decltype(i_)::value;
+                __builtin_amdgcn_global_load_lds((const NRF_GLB void*)g, (NRF_LDS void*)l, 16, i * kFragBytes, 0);
+            });
         }
         issue_chunk = (issue_chunk + 1 == n_chunks) ? 0u : issue_chunk + 1;
         issue_slot = (issue_slot + 1 == (uint32_t)kSlots) ? 0u : issue_slot + 1;
@@ -141,9 +150,15 @@ struct Pipe {
     // make the next chunk of the stream readable through base[parity]
     __device__ __forceinline__ void acquire(int parity) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFragsPerWave * (kAhead - 1)) : "memory");
+#ifdef NRF_ABLATE_BUILD
         if (!(ablate & 2)) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (!(ablate & 1)) issue_one();
+#else
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        issue_one();
+#endif
         base[parity] = ring + read_slot * kChunkBytes + lane_off;
         read_slot = (read_slot + 1 == (uint32_t)kSlots) ? 0u : read_slot + 1;
     }
@@ -390,12 +405,30 @@ __device__ __forceinline__ void dense(P& pipe, const NRF_LDS float* bias, int h,
 // rides in the shadow of the MFMAs (an MFMA holds the issue port for 8 of its 32 cycles).  The bias of the tile after next is
 // fetched in the step behind the last slice (its accumulator set is free from then on).  With the LDS-DMA issued as inline asm
 // (Pipe<..., ASM_DMA>) hipcc's waitcnt pass sees a pure in-order ds_read stream and emits counted lgkmcnt waits.
-template <class Mode, int KT, int MT, int NT, class P, class FinSlice>
-__device__ __forceinline__ void dense_pinned(P& pipe, const NRF_LDS float* bias, int h,
-                                             const typename Mode::Act (&in)[KT][NT], FinSlice&& fin) {
+//
+// Chained layers.  What is left exposed is the layer boundary: the eight slices of the LAST tile (nothing behind them to hide in),
+// the first fragment reads and the first bias fetch of the next layer (LDS latency with an empty MFMA queue).  A layer can
+// therefore hand a Carry to the next one (COUT / CIN):
+//   kCarryPre : the next layer's first PF fragments (read during this layer's last PF steps -- the stream is continuous, the
+//               next layer starts on the next chunk) and its tile-0 bias (fetched where a tile m+1 bias would be);
+//   kCarryTail: additionally the last tile's RAW accumulators; the next layer converts them, `tail(j)`, in the slice steps of
+//               its tile 0 -- the operand tile they complete is first read (KT-1)*SUB steps in, long after.
+enum { kCarryNone = 0, kCarryPre = 1, kCarryTail = 2 };
+
+template <class Mode, int NT>
+struct Carry {
+    f32x16 tail[NT];
+    f32x16 bias0;
+    typename Mode::frag_t fr[kPrefetch];
+};
+
+template <class Mode, int KT, int MT, int NT, int CIN, int COUT, int TAIL_TILE, class P, class FinSlice, class TailSlice>
+__device__ __forceinline__ void dense_pinned(P& pipe, const NRF_LDS float* bias, const NRF_LDS float* bias_next, int h,
+                                             const typename Mode::Act (&in)[KT][NT], FinSlice&& fin, TailSlice&& tail, Carry<Mode, NT>& carry) {
     constexpr int PER_M = KT * Mode::SUB;
     constexpr int NF = MT * PER_M;
-    constexpr int PF = NF < kPrefetch ? NF : kPrefetch;
+    constexpr int PF = kPrefetch;
+    static_assert(NF >= PF, "layer shorter than the fragment prefetch");
     constexpr int EPI = PER_M > kEpilogueAt + 1 ? kEpilogueAt : 1;      // first slice step: tile m-1's last MFMAs have drained
     constexpr int ROOM = PER_M - EPI - 1;                               // steps that may carry slices (one more is the bias step)
     static_assert(ROOM >= 1, "layer too short for the sliced epilogue");
@@ -403,18 +436,25 @@ __device__ __forceinline__ void dense_pinned(P& pipe, const NRF_LDS float* bias,
     constexpr int NSTEP = (8 + SPS - 1) / SPS;
     constexpr int BIAS_AT = EPI + NSTEP;
     static_assert(BIAS_AT < PER_M, "no step left for the bias fetch");
+    static_assert(CIN != kCarryTail || EPI + NSTEP <= TAIL_TILE * Mode::SUB, "the carried tile is read before its slices are done");
     typedef typename Mode::frag_t frag_t;
-    frag_t fr[PF];
+    frag_t fr[PF], nxt[PF];
     auto read = [&](auto g_) -> frag_t {
         constexpr int g = decltype(g_)::value;
         if constexpr (g % kChunkFrags == 0) pipe.acquire((g / kChunkFrags) & 1);
         return *(const NRF_LDS frag_t*)(pipe.base[(g / kChunkFrags) & 1] + (g % kChunkFrags) * kFragBytes);
     };
-    static_for<PF>([&](auto i_) { fr[decltype(i_)::value] = read(i_); });
     f32x16 acc[2][NT];
-    load_bias(acc[0][0], bias, h);
+    if constexpr (CIN != kCarryNone) {
+        static_for<PF>([&](auto i_) { fr[decltype(i_)::value] = carry.fr[decltype(i_)::value]; });
+        acc[0][0] = carry.bias0;
+    } else {
+        static_for<PF>([&](auto i_) { fr[decltype(i_)::value] = read(i_); });
+        load_bias(acc[0][0], bias, h);
+    }
 #pragma unroll
     for (int n = 1; n < NT; ++n) acc[0][n] = acc[0][0];
+    f32x16 bias0_next;
     __builtin_amdgcn_sched_barrier(0);
     static_for<NF>([&](auto f_) {
         constexpr int f = decltype(f_)::value;
@@ -423,32 +463,56 @@ __device__ __forceinline__ void dense_pinned(P& pipe, const NRF_LDS float* bias,
 #pragma unroll
         for (int n = 0; n < NT; ++n) Mode::mma(acc[m & 1][n], a, in[t][n], s);
         if constexpr (f + PF < NF) fr[f % PF] = read(std::integral_constant<int, f + PF>{});
-        if constexpr (m > 0 && rem >= EPI && rem < EPI + NSTEP) {
+        else if constexpr (COUT != kCarryNone) nxt[f + PF - NF] = read(std::integral_constant<int, f + PF - NF>{});   // the next layer's fragment: its chunk 0, parity 0
+        if constexpr ((m > 0 || CIN == kCarryTail) && rem >= EPI && rem < EPI + NSTEP) {
             static_for<SPS>([&](auto k_) {
                 constexpr int j = (rem - EPI) * SPS + decltype(k_)::value;
-                if constexpr (j < 8) fin(std::integral_constant<int, m - 1>{}, acc[(m - 1) & 1], std::integral_constant<int, j>{});
+                if constexpr (j < 8) {
+                    if constexpr (m > 0) fin(std::integral_constant<int, m - 1>{}, acc[(m - 1) & 1], std::integral_constant<int, j>{});
+                    else tail(carry.tail, std::integral_constant<int, j>{});
+                }
             });
         }
-        if constexpr (rem == BIAS_AT && m + 1 < MT) {
-            load_bias(acc[(m + 1) & 1][0], bias + 32 * (m + 1), h);
+        if constexpr (rem == BIAS_AT) {
+            if constexpr (m + 1 < MT) {
+                load_bias(acc[(m + 1) & 1][0], bias + 32 * (m + 1), h);
 #pragma unroll
-            for (int n = 1; n < NT; ++n) acc[(m + 1) & 1][n] = acc[(m + 1) & 1][0];
+                for (int n = 1; n < NT; ++n) acc[(m + 1) & 1][n] = acc[(m + 1) & 1][0];
+            } else if constexpr (COUT != kCarryNone) {
+                load_bias(bias0_next, bias_next, h);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     });
-    static_for<8>([&](auto j_) { fin(std::integral_constant<int, MT - 1>{}, acc[(MT - 1) & 1], j_); });
+    if constexpr (COUT != kCarryNone) {
+        static_for<PF>([&](auto i_) { carry.fr[decltype(i_)::value] = nxt[decltype(i_)::value]; });
+        carry.bias0 = bias0_next;
+    }
+    if constexpr (COUT == kCarryTail) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) carry.tail[n] = acc[(MT - 1) & 1][n];
+    } else {
+        static_for<8>([&](auto j_) { fin(std::integral_constant<int, MT - 1>{}, acc[(MT - 1) & 1], j_); });
+    }
 }
 
-// layer with an activation, producing the next layer's operand tiles
-template <class Mode, int KT, int MT, int NT, bool RELU, class P>
-__device__ __forceinline__ void dense_act(P& pipe, const NRF_LDS float* bias, int h,
-                                          const typename Mode::Act (&in)[KT][NT], typename Mode::Act (&out)[MT][NT]) {
+// layer with an activation, producing the next layer's operand tiles.  Chained form: `carry` links it to its neighbours in a
+// pinned walk (ignored -- every layer complete in itself -- by the two-waves-per-SIMD and fp32 walks).  TAIL_RELU / TAIL_TILE: the
+// activation of the layer that left its last tile in `carry`, and the operand tile of `in` that tile completes.
+template <class Mode, int KT, int MT, int NT, bool RELU, int CIN, int COUT, bool TAIL_RELU = true, int TAIL_TILE = KT - 1, class P>
+__device__ __forceinline__ void dense_act_chain(P& pipe, const NRF_LDS float* bias, const NRF_LDS float* bias_next, int h,
+                                                typename Mode::Act (&in)[KT][NT], typename Mode::Act (&out)[MT][NT], Carry<Mode, NT>& carry) {
     if constexpr (pinned_walk<Mode, NT>()) {
-        dense_pinned<Mode, KT, MT, NT>(pipe, bias, h, in, [&](auto m_, f32x16(&acc)[NT], auto j_) {
-            constexpr int m = decltype(m_)::value;
+        dense_pinned<Mode, KT, MT, NT, CIN, COUT, TAIL_TILE>(pipe, bias, bias_next, h, in,
+            [&](auto m_, f32x16(&acc)[NT], auto j_) {
+                constexpr int m = decltype(m_)::value;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) Mode::template to_act_pair<RELU>(acc[n], decltype(j_)::value, out[m][n]);
-        });
+                for (int n = 0; n < NT; ++n) Mode::template to_act_pair<RELU>(acc[n], decltype(j_)::value, out[m][n]);
+            },
+            [&](f32x16(&tl)[NT], auto j_) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) Mode::template to_act_pair<TAIL_RELU>(tl[n], decltype(j_)::value, in[TAIL_TILE][n]);
+            }, carry);
     } else {
         dense<Mode, KT, MT, NT>(pipe, bias, h, in, [&](auto m_, f32x16(&acc)[NT]) {
             constexpr int m = decltype(m_)::value;
@@ -458,22 +522,44 @@ __device__ __forceinline__ void dense_act(P& pipe, const NRF_LDS float* bias, in
     }
 }
 
+template <class Mode, int KT, int MT, int NT, bool RELU, class P>
+__device__ __forceinline__ void dense_act(P& pipe, const NRF_LDS float* bias, int h,
+                                          const typename Mode::Act (&in)[KT][NT], typename Mode::Act (&out)[MT][NT]) {
+    typedef typename Mode::Act Act;
+    Carry<Mode, NT> none;      // unchained: `in` is only read
+    dense_act_chain<Mode, KT, MT, NT, RELU, kCarryNone, kCarryNone>(pipe, bias, bias, h, const_cast<Act(&)[KT][NT]>(in), out, none);
+}
+
 // head layer: one output tile, raw accumulators back to the caller
-template <class Mode, int KT, int NT, class P>
-__device__ __forceinline__ void dense_head(P& pipe, const NRF_LDS float* bias, int h,
-                                           const typename Mode::Act (&in)[KT][NT], f32x16 (&out)[NT]) {
+template <class Mode, int KT, int NT, int CIN, int COUT, bool TAIL_RELU = true, int TAIL_TILE = KT - 1, class P>
+__device__ __forceinline__ void dense_head_chain(P& pipe, const NRF_LDS float* bias, const NRF_LDS float* bias_next, int h,
+                                                 typename Mode::Act (&in)[KT][NT], f32x16 (&out)[NT], Carry<Mode, NT>& carry) {
+    static_assert(COUT != kCarryTail, "a head hands its tile to the caller");
     if constexpr (pinned_walk<Mode, NT>()) {
-        dense_pinned<Mode, KT, 1, NT>(pipe, bias, h, in, [&](auto, f32x16(&acc)[NT], auto j_) {
-            constexpr int j = decltype(j_)::value;
+        dense_pinned<Mode, KT, 1, NT, CIN, COUT, TAIL_TILE>(pipe, bias, bias_next, h, in,
+            [&](auto, f32x16(&acc)[NT], auto j_) {
+                constexpr int j = decltype(j_)::value;
 #pragma unroll
-            for (int n = 0; n < NT; ++n) { out[n][2 * j] = acc[n][2 * j]; out[n][2 * j + 1] = acc[n][2 * j + 1]; }
-        });
+                for (int n = 0; n < NT; ++n) { out[n][2 * j] = acc[n][2 * j]; out[n][2 * j + 1] = acc[n][2 * j + 1]; }
+            },
+            [&](f32x16(&tl)[NT], auto j_) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n) Mode::template to_act_pair<TAIL_RELU>(tl[n], decltype(j_)::value, in[TAIL_TILE][n]);
+            }, carry);
     } else {
         dense<Mode, KT, 1, NT>(pipe, bias, h, in, [&](auto, f32x16(&acc)[NT]) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) out[n] = acc[n];
         });
     }
+}
+
+template <class Mode, int KT, int NT, class P>
+__device__ __forceinline__ void dense_head(P& pipe, const NRF_LDS float* bias, int h,
+                                           const typename Mode::Act (&in)[KT][NT], f32x16 (&out)[NT]) {
+    typedef typename Mode::Act Act;
+    Carry<Mode, NT> none;
+    dense_head_chain<Mode, KT, NT, kCarryNone, kCarryNone>(pipe, bias, bias, h, const_cast<Act(&)[KT][NT]>(in), out, none);
 }
 
 constexpr __host__ __device__ int chunks_for(int frags) { return (frags + kChunkFrags - 1) / kChunkFrags; }

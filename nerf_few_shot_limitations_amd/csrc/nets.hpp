@@ -107,26 +107,29 @@ struct NetV1 {
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
                                                 Inputs&& inputs, Dirs&&, float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
+        // the layers of a pass are chained (mlp_core.hpp "Chained layers"): each leaves its last tile and the next layer's first
+        // fragments / bias in `cy`
+        Carry<Mode, NT> cy;
         {
             Act enc[KT0][NT];
             float one[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) one[n] = 1.0f;
             inputs(one, one, enc);
-            dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);
+            dense_act_chain<Mode, KT0, HT, NT, true, kCarryNone, kCarryTail>(pipe, bias, bias + 32 * HT, h, enc, A, cy);
         }
         int boff = 32 * HT;
         const int hidden = n_layers - 1;
         for (int p = 0; p < hidden / 2; ++p) {
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, B, A); boff += 32 * HT;
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, B, A, cy); boff += 32 * HT;
         }
         f32x16 head[NT];
         if (hidden & 1) {
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-            dense_head<Mode, HT, NT>(pipe, bias + boff, h, B, head);
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+            dense_head_chain<Mode, HT, NT, kCarryTail, kCarryNone>(pipe, bias + boff, bias + boff, h, B, head, cy);
         } else {
-            dense_head<Mode, HT, NT>(pipe, bias + boff, h, A, head);
+            dense_head_chain<Mode, HT, NT, kCarryTail, kCarryNone>(pipe, bias + boff, bias + boff, h, A, head, cy);
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n)
@@ -148,17 +151,22 @@ struct NetV2 {
 
     // density_head, feature_head, colour layers; X = trunk output, Y = scratch of the same shape
     // `dir(tile)` builds the direction-encoding tile only now, right before the colour branch needs it: its
-    // registers are not held across the trunk
-    template <class P, class Dirs>
-    __device__ static __forceinline__ void tail(P& pipe, const NRF_LDS float* bias, int h, const Act (&X)[HT][NT],
-                                                Act (&Y)[HT][NT], Dirs&& dir, float (&out4)[NT][4]) {
+    // registers are not held across the trunk.  CIN = kCarryTail: the trunk's last layer left X's last tile (and this branch's
+    // first fragments / bias) in `cy` (chained layers, mlp_core.hpp); the layers of the branch are chained among themselves.
+    template <int CIN, class P, class Dirs>
+    __device__ static __forceinline__ void tail(P& pipe, const NRF_LDS float* bias, int h, Act (&X)[HT][NT],
+                                                Act (&Y)[HT][NT], Dirs&& dir, float (&out4)[NT][4], Carry<Mode, NT>& cy) {
+        const NRF_LDS float* b_feat = bias + 32;
+        const NRF_LDS float* b_c0 = b_feat + 32 * HT;
+        const NRF_LDS float* b_c1 = b_c0 + 16 * HT;
+        const NRF_LDS float* b_rgb = b_c1 + 8 * HT;
         {   // keep only the density scalar alive across the colour branch, not its 16-register tile
             f32x16 dens[NT];
-            dense_head<Mode, HT, NT>(pipe, bias, h, X, dens);
+            dense_head_chain<Mode, HT, NT, CIN, kCarryPre>(pipe, bias, b_feat, h, X, dens, cy);
 #pragma unroll
             for (int n = 0; n < NT; ++n) out4[n][3] = dens[n][0];
         }
-        dense_act<Mode, HT, HT, NT, false>(pipe, bias + 32, h, X, Y);                     // feature_head: no activation
+        dense_act_chain<Mode, HT, HT, NT, false, kCarryPre, kCarryTail>(pipe, b_feat, b_c0, h, X, Y, cy);      // feature_head: no activation
         Act in9[HT + 1][NT];
 #pragma unroll
         for (int t = 0; t < HT; ++t)
@@ -171,10 +179,11 @@ struct NetV2 {
             for (int n = 0; n < NT; ++n) in9[HT][n] = dt[0][n];
         }
         Act c0[HT / 2][NT], c1[HT / 4][NT];
-        dense_act<Mode, HT + 1, HT / 2, NT, true>(pipe, bias + 32 + 32 * HT, h, in9, c0);
-        dense_act<Mode, HT / 2, HT / 4, NT, true>(pipe, bias + 32 + 32 * HT + 16 * HT, h, c0, c1);
+        // the feature tile still in `cy` is operand tile HT-1 of the concatenation, produced without activation
+        dense_act_chain<Mode, HT + 1, HT / 2, NT, true, kCarryTail, kCarryPre, false, HT - 1>(pipe, b_c0, b_c1, h, in9, c0, cy);
+        dense_act_chain<Mode, HT / 2, HT / 4, NT, true, kCarryPre, kCarryPre>(pipe, b_c1, b_rgb, h, c0, c1, cy);
         f32x16 rgb[NT];
-        dense_head<Mode, HT / 4, NT>(pipe, bias + 32 + 32 * HT + 16 * HT + 8 * HT, h, c1, rgb);
+        dense_head_chain<Mode, HT / 4, NT, kCarryPre, kCarryNone>(pipe, b_rgb, b_rgb, h, c1, rgb, cy);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             out4[n][0] = rgb[n][0]; out4[n][1] = rgb[n][1]; out4[n][2] = rgb[n][2];
@@ -185,25 +194,26 @@ struct NetV2 {
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
                                                 Inputs&& inputs, Dirs&& dir, float (&out4)[NT][4]) {
         Act A[HT][NT], B[HT][NT];
+        Carry<Mode, NT> cy;
         {
             Act enc[KT0][NT];
             float one[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) one[n] = 1.0f;
             inputs(one, one, enc);
-            dense_act<Mode, KT0, HT, NT, true>(pipe, bias, h, enc, A);
+            dense_act_chain<Mode, KT0, HT, NT, true, kCarryNone, kCarryTail>(pipe, bias, bias + 32 * HT, h, enc, A, cy);
         }
         int boff = 32 * HT;
         const int hidden = n_layers - 1;
         for (int p = 0; p < hidden / 2; ++p) {
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, B, A); boff += 32 * HT;
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, B, A, cy); boff += 32 * HT;
         }
         if (hidden & 1) {
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-            tail(pipe, bias + boff, h, B, A, dir, out4);
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+            tail<kCarryTail>(pipe, bias + boff, h, B, A, dir, out4, cy);
         } else {
-            tail(pipe, bias + boff, h, A, B, dir, out4);
+            tail<kCarryTail>(pipe, bias + boff, h, A, B, dir, out4, cy);
         }
     }
 };
@@ -262,11 +272,12 @@ struct NetV3 {
             dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
             dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, B, A); boff += 32 * HT;
         }
+        Carry<Mode, NT> none;
         if (n_layers & 1) {
             dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-            NetV2<Mode, NT, LP>::tail(pipe, bias + boff, h, B, A, dir, out4);
+            NetV2<Mode, NT, LP>::template tail<kCarryNone>(pipe, bias + boff, h, B, A, dir, out4, none);
         } else {
-            NetV2<Mode, NT, LP>::tail(pipe, bias + boff, h, A, B, dir, out4);
+            NetV2<Mode, NT, LP>::template tail<kCarryNone>(pipe, bias + boff, h, A, B, dir, out4, none);
         }
     }
 };

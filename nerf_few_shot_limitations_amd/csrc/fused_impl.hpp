@@ -748,34 +748,55 @@ bool check_net(const DeviceNet& net, int mode, std::string& err) {
 //     per pass) is latency one wave per SIMD cannot cover (4 x 64: -3...5 %).
 //   * fp32 and split-f16: 4 waves x 32 columns (their activations take 16 registers per tile).
 // The images are bit-identical across geometries (tools/image_hash.py): a column's arithmetic does not depend on where it sits.
+// Each family's translation unit is compiled twice (build.py): NRF_TU_HALF == 16 holds the two 16-bit modes (VGPR-form MFMAs,
+// operand images parked in AGPRs), NRF_TU_HALF == 32 the fp32-class modes; fused_kernels.hip routes by mode.
+#if !defined(NRF_TU_HALF)
+// (fused_kernels.hip: routing only, no kernels)
+#elif NRF_TU_HALF == 16
+#define NRF_TU_NAME(f) f##_16
 #define NRF_DISPATCH_MODE(FN, NET, LP, ...)                                                                 \
     switch (mode) {                                                                                         \
         case NRF_MMA_BF16: return FN<NET<ModeBF16, 2, LP>, ModeBF16, 2, 4, LP, 4>(__VA_ARGS__);             \
-        case NRF_MMA_F16:  return FN<NET<ModeF16, 2, LP>, ModeF16, 2, 4, LP, 4>(__VA_ARGS__);               \
-        case NRF_MMA_F16X3: return FN<NET<ModeF16X3, 1, LP>, ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);         \
-        default: return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                         \
+        default:           return FN<NET<ModeF16, 2, LP>, ModeF16, 2, 4, LP, 4>(__VA_ARGS__);               \
     }
-
 // V2 / V3 (NT16, WAVES16: the 16-bit modes' geometry)
 #define NRF_DISPATCH_MODE1(FN, NETT, LP, NT16, WAVES16, ...)                                                \
     switch (mode) {                                                                                         \
         case NRF_MMA_BF16: return FN<NETT(ModeBF16, NT16), ModeBF16, NT16, WAVES16, LP, 4>(__VA_ARGS__);    \
-        case NRF_MMA_F16:  return FN<NETT(ModeF16, NT16), ModeF16, NT16, WAVES16, LP, 4>(__VA_ARGS__);      \
-        case NRF_MMA_F16X3: return FN<NETT(ModeF16X3, 1), ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);           \
-        default:           return FN<NETT(ModeF32, 1), ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                  \
+        default:           return FN<NETT(ModeF16, NT16), ModeF16, NT16, WAVES16, LP, 4>(__VA_ARGS__);      \
     }
+#else
+#define NRF_TU_NAME(f) f##_32
+#define NRF_DISPATCH_MODE(FN, NET, LP, ...)                                                                 \
+    switch (mode) {                                                                                         \
+        case NRF_MMA_F16X3: return FN<NET<ModeF16X3, 1, LP>, ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);         \
+        default:            return FN<NET<ModeF32, 1, LP>, ModeF32, 1, 4, LP, 4>(__VA_ARGS__);              \
+    }
+#define NRF_DISPATCH_MODE1(FN, NETT, LP, NT16, WAVES16, ...)                                                \
+    switch (mode) {                                                                                         \
+        case NRF_MMA_F16X3: return FN<NETT(ModeF16X3, 1), ModeF16X3, 1, 4, LP, 4>(__VA_ARGS__);           \
+        default:            return FN<NETT(ModeF32, 1), ModeF32, 1, 4, LP, 4>(__VA_ARGS__);                 \
+    }
+#endif
 #define NRF_NET_V2_10(M, NT) NetV2<M, NT, 10>
 #define NRF_NET_V3_12_64(M, NT) NetV3<M, NT, 12, 2>
 #define NRF_NET_V3_12_128(M, NT) NetV3<M, NT, 12, 4>
 
-// per-family entry points, one translation unit each (fused_v1.hip ... fused_v3w.hip) so that hipcc builds them in parallel
-int render_v1(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
-int render_v2(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
-int render_v3(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
-int render_v3w(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);
-int forward_v1(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
-int forward_v2(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
-int forward_v3(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
-int forward_v3w(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);
+// per-family entry points, two translation units each (fused_v1.hip ... fused_v3w.hip x the two halves) so that hipcc builds them in parallel
+#define NRF_DECLARE_FAMILY(fam)                                                                                            \
+    int render_##fam##_16(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);           \
+    int render_##fam##_32(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err);           \
+    int forward_##fam##_16(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);               \
+    int forward_##fam##_32(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err);               \
+    inline int render_##fam(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) {        \
+        return (mode == NRF_MMA_BF16 || mode == NRF_MMA_F16) ? render_##fam##_16(net, mode, a, s, err) : render_##fam##_32(net, mode, a, s, err); \
+    }                                                                                                                      \
+    inline int forward_##fam(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) {            \
+        return (mode == NRF_MMA_BF16 || mode == NRF_MMA_F16) ? forward_##fam##_16(net, mode, k, s, err) : forward_##fam##_32(net, mode, k, s, err); \
+    }
+NRF_DECLARE_FAMILY(v1)
+NRF_DECLARE_FAMILY(v2)
+NRF_DECLARE_FAMILY(v3)
+NRF_DECLARE_FAMILY(v3w)
 
 }  // namespace nrf

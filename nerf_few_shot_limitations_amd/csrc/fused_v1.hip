@@ -3,7 +3,7 @@
 
 namespace nrf {
 
-int render_v1(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE(run_render, NetV1, 10, net, mode, a, s, err) }
-int forward_v1(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE(run_forward, NetV1, 10, net, mode, k, s, err) }
+int NRF_TU_NAME(render_v1)(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE(run_render, NetV1, 10, net, mode, a, s, err) }
+int NRF_TU_NAME(forward_v1)(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE(run_forward, NetV1, 10, net, mode, k, s, err) }
 
 }  // namespace nrf

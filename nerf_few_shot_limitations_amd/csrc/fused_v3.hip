@@ -3,7 +3,7 @@
 
 namespace nrf {
 
-int render_v3(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE1(run_render, NRF_NET_V3_12_64, 12, 1, 8, net, mode, a, s, err) }
-int forward_v3(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE1(run_forward, NRF_NET_V3_12_64, 12, 1, 8, net, mode, k, s, err) }
+int NRF_TU_NAME(render_v3)(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE1(run_render, NRF_NET_V3_12_64, 12, 1, 8, net, mode, a, s, err) }
+int NRF_TU_NAME(forward_v3)(const DeviceNet& net, int mode, ForwardKArgs k, hipStream_t s, std::string& err) { NRF_DISPATCH_MODE1(run_forward, NRF_NET_V3_12_64, 12, 1, 8, net, mode, k, s, err) }
 
 }  // namespace nrf

@@ -61,6 +61,17 @@ constexpr int kChunkFrags = NRF_CHUNK_FRAGS;
 constexpr int kChunkBytes = kFragBytes * kChunkFrags;  // 16 KiB
 constexpr int kSlots = NRF_SLOTS;                      // ring depth (128 KiB)
 
+// An epilogue slice of the pinned walk ends in an empty, opaque asm on the words it produced (see ModeF16X3::to_act_pair).
+#define NRF_PIN_ACT1(a) asm volatile("" : "+v"(a))
+#define NRF_PIN_ACT2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+// ... and, when the translation unit is built with VGPR-form MFMAs (-mllvm -amdgpu-mfma-vgpr-form=1, -DNRF_ACT_AGPR), a finished
+// 128-bit operand image is moved to the AGPR half of the register file, where the next layer's MFMAs read it directly
+#ifdef NRF_ACT_AGPR
+#define NRF_PARK_ACT(v) asm volatile("" : "+a"(v))
+#else
+#define NRF_PARK_ACT(v)
+#endif
+
 template <class F, int... I>
 __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -194,9 +205,10 @@ struct ModeBF16 {
     template <bool RELU>
     __device__ static __forceinline__ void to_act_pair(const f32x16& v, int j, Act& o) {     // dense_pinned's epilogue slice
         int nw = pack_pair<bf16x2, RELU>(v[2 * j], v[2 * j + 1]);
-        asm volatile("" : "+v"(nw));
+        NRF_PIN_ACT1(nw);
         i32x4 w = __builtin_bit_cast(i32x4, o.f[j >> 2]);
         w[j & 3] = nw;
+        if ((j & 3) == 3) NRF_PARK_ACT(w);
         o.f[j >> 2] = __builtin_bit_cast(bf16x8, w);
     }
 };
@@ -226,9 +238,10 @@ struct ModeF16 {
     template <bool RELU>
     __device__ static __forceinline__ void to_act_pair(const f32x16& v, int j, Act& o) {     // dense_pinned's epilogue slice
         int nw = pack_pair<f16x2, RELU>(v[2 * j], v[2 * j + 1]);
-        asm volatile("" : "+v"(nw));
+        NRF_PIN_ACT1(nw);
         i32x4 w = __builtin_bit_cast(i32x4, o.f[j >> 2]);
         w[j & 3] = nw;
+        if ((j & 3) == 3) NRF_PARK_ACT(w);
         o.f[j >> 2] = __builtin_bit_cast(f16x8, w);
     }
 };
@@ -312,7 +325,7 @@ struct ModeF16X3 {
         int nh = __builtin_bit_cast(int, hh), nl = __builtin_bit_cast(int, __builtin_convertvector(rest, f16x2));
         // the words are first USED by the next layer: without this (empty, opaque) statement LLVM sinks the whole slice down to
         // that use, across the step fences, and the epilogues of several tiles pile up between two MFMAs again
-        asm volatile("" : "+v"(nh), "+v"(nl));
+        NRF_PIN_ACT2(nh, nl);
         i32x4 wh = __builtin_bit_cast(i32x4, o.hi[s]), wl = __builtin_bit_cast(i32x4, o.lo[s]);
         wh[w] = nh;
         wl[w] = nl;

@@ -1,5 +1,5 @@
 #!/bin/bash
-# same-box A/B of library variants (tools/build_variant_v1.sh): tools/ab_variants.sh base pf2 pf5 ...
+# same-box A/B of library variants (tools/build_variant.sh): tools/ab_variants.sh base pf2 pf5 ...
 for v in "$@"; do
   lib=nerf_few_shot_limitations_amd/libnerfhip_$v.so
   [ "$v" = base ] && lib=nerf_few_shot_limitations_amd/libnerfhip.so

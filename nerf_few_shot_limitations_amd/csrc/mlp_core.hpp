@@ -173,6 +173,39 @@ struct Pipe {
         base[parity] = ring + read_slot * kChunkBytes + lane_off;
         read_slot = (read_slot + 1 == (uint32_t)kSlots) ? 0u : read_slot + 1;
     }
+    // The pinned walk's form of acquire(): the barrier and the first of this wave's kFragsPerWave LDS-DMA instructions now, the
+    // others one per fragment step (issue_part<k>() rides with the read of fragment k of the chunk).  Back to back behind the
+    // barrier, the four 1-KiB DMA instructions held the wave's issue port for ~100 cycles with an empty MFMA queue (one wave per
+    // SIMD); spread out, each sits in the shadow of its step's MFMAs (+0.8 % bf16, +1.7 % split-f16).  What the stream still costs
+    // (-6 % by ablation, proportional to the number of DMA instructions) is not the issue port: the four waves, released
+    // together by the chunk barrier, reach every DMA instruction at the same moment.  Giving each wave its own steps
+    // (a wave-id test per step) costs more than it saves: -9 % (profiles/r02_ab_dma_issue.txt).
+    const NRF_GLB char* dma_g;
+    uint32_t dma_m0;
+    __device__ __forceinline__ void acquire_begin(int parity) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kFragsPerWave * (kAhead - 1)) : "memory");
+#ifdef NRF_ABLATE_BUILD
+        if (!(ablate & 2))
+#endif
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        dma_g = src + (size_t)issue_chunk * kChunkBytes;
+        dma_m0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(ring + issue_slot * kChunkBytes + wave_off));
+        issue_chunk = (issue_chunk + 1 == n_chunks) ? 0u : issue_chunk + 1;
+        issue_slot = (issue_slot + 1 == (uint32_t)kSlots) ? 0u : issue_slot + 1;
+        base[parity] = ring + read_slot * kChunkBytes + lane_off;
+        read_slot = (read_slot + 1 == (uint32_t)kSlots) ? 0u : read_slot + 1;
+        issue_part<0>();
+    }
+    template <int K>
+    __device__ __forceinline__ void issue_part() {
+        static_assert(ASM_DMA && K < kFragsPerWave, "issue_part: the pinned walk's pipe");
+#ifdef NRF_ABLATE_BUILD
+        if ((ablate & 1) || ((ablate & 4) && K >= 1) || ((ablate & 8) && K >= 2)) return;      // 4 / 8: a quarter / half of the DMA instructions (vmcnt no longer counts right: pair with 2)
+#endif
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
+                     : : "v"(dma_g), "s"(dma_m0), "n"(K * kFragBytes) : "memory", "m0");
+    }
     // all LDS-DMA must have landed before the workgroup gives its LDS back
     __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
@@ -452,9 +485,12 @@ __device__ __forceinline__ void dense_pinned(P& pipe, const NRF_LDS float* bias,
     static_assert(CIN != kCarryTail || EPI + NSTEP <= TAIL_TILE * Mode::SUB, "the carried tile is read before its slices are done");
     typedef typename Mode::frag_t frag_t;
     frag_t fr[PF], nxt[PF];
+    // a layer's last chunk must see all of its DMA parts issued (they ride with the reads of its first fragments)
+    static_assert((NF % kChunkFrags == 0 ? kChunkFrags : NF % kChunkFrags) >= P::kFragsPerWave, "last chunk of the layer too short for the spread LDS-DMA issue");
     auto read = [&](auto g_) -> frag_t {
         constexpr int g = decltype(g_)::value;
-        if constexpr (g % kChunkFrags == 0) pipe.acquire((g / kChunkFrags) & 1);
+        if constexpr (g % kChunkFrags == 0) pipe.acquire_begin((g / kChunkFrags) & 1);
+        else if constexpr (g % kChunkFrags < P::kFragsPerWave) pipe.template issue_part<g % kChunkFrags>();
         return *(const NRF_LDS frag_t*)(pipe.base[(g / kChunkFrags) & 1] + (g % kChunkFrags) * kFragBytes);
     };
     f32x16 acc[2][NT];

@@ -741,11 +741,12 @@ bool check_net(const DeviceNet& net, int mode, std::string& err) {
 
 // Workgroup geometry per arithmetic mode and network family (NT sample tiles per wave, WAVES).  Every geometry marches 256
 // sample columns per workgroup and weight pass.
-//   * 16-bit modes, V1 / V2: 4 waves x 64 columns, one wave per SIMD on the whole 512-entry register file, pinned walk.  A fragment
-//     read from LDS feeds two MFMAs (half the LDS bytes per FLOP), and nothing spills (the 8 x 32 build of V2 carried 40-50
-//     spilled registers): V2 +8 %, V1 +1...2 % over 8 x 32 on the same box (profiles/r02_ab_wide16.txt).
-//   * 16-bit modes, V3: 8 waves x 32 columns, two per SIMD, hipcc's schedule: its per-pass feature-map gather (global loads, twice
-//     per pass) is latency one wave per SIMD cannot cover (4 x 64: -3...5 %).
+//   * 16-bit modes: 4 waves x 64 columns, one wave per SIMD on the whole 512-entry register file, pinned walk.  A fragment
+//     read from LDS feeds two MFMAs (half the LDS bytes per FLOP), finished operand images are parked in the AGPR half
+//     (mlp_core.hpp NRF_PARK_ACT) and nothing of the walk spills (the 8 x 32 builds of V2 / V3 carried 40-50 spilled registers).
+//     Against 8 x 32 on the same box: V2 +8 %, V1 +1...2 % as first built (profiles/r02_ab_wide16.txt), then +3.6 % (chained
+//     layers), +2.7 % (AGPR operands), +0.8 % (spread LDS-DMA issue); V3 +3 % (its per-pass feature-map gather -- global loads,
+//     twice per pass -- is latency one wave per SIMD cannot cover: profiles/r02_ab_v3_geometry.txt).
 //   * fp32 and split-f16: 4 waves x 32 columns (their activations take 16 registers per tile).
 // The images are bit-identical across geometries (tools/image_hash.py): a column's arithmetic does not depend on where it sits.
 // Each family's translation unit is compiled twice (build.py): NRF_TU_HALF == 16 holds the two 16-bit modes (VGPR-form MFMAs,

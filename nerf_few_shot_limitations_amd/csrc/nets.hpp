@@ -153,7 +153,7 @@ struct NetV2 {
     // `dir(tile)` builds the direction-encoding tile only now, right before the colour branch needs it: its
     // registers are not held across the trunk.  CIN = kCarryTail: the trunk's last layer left X's last tile (and this branch's
     // first fragments / bias) in `cy` (chained layers, mlp_core.hpp); the layers of the branch are chained among themselves.
-    template <int CIN, class P, class Dirs>
+    template <int CIN, bool TAIL_RELU = true, class P, class Dirs>
     __device__ static __forceinline__ void tail(P& pipe, const NRF_LDS float* bias, int h, Act (&X)[HT][NT],
                                                 Act (&Y)[HT][NT], Dirs&& dir, float (&out4)[NT][4], Carry<Mode, NT>& cy) {
         const NRF_LDS float* b_feat = bias + 32;
@@ -162,7 +162,7 @@ struct NetV2 {
         const NRF_LDS float* b_rgb = b_c1 + 8 * HT;
         {   // keep only the density scalar alive across the colour branch, not its 16-register tile
             f32x16 dens[NT];
-            dense_head_chain<Mode, HT, NT, CIN, kCarryPre>(pipe, bias, b_feat, h, X, dens, cy);
+            dense_head_chain<Mode, HT, NT, CIN, kCarryPre, TAIL_RELU>(pipe, bias, b_feat, h, X, dens, cy);
 #pragma unroll
             for (int n = 0; n < NT; ++n) out4[n][3] = dens[n][0];
         }
@@ -242,18 +242,27 @@ struct NetV3 {
         float w0[NT], w1[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) w0[n] = w1[n] = 1.0f;
-        int boff = 0;
+        // chained layers (mlp_core.hpp): bias offsets of the walk, in stream order
+        const NRF_LDS float* b_f1 = bias;                       // fusion layer 1 (first pass)
+        const NRF_LDS float* b_f2 = b_f1 + 32 * HT;             // fusion layer 2
+        const NRF_LDS float* b_a0 = b_f2 + 32 * HT;             // attention hidden (HT/4 tiles)
+        const NRF_LDS float* b_a1 = b_a0 + 8 * HT;              // attention logits (one tile)
+        const NRF_LDS float* b_g1 = b_a1 + 32;                  // fusion layer 1 (second pass, gated inputs)
+        const NRF_LDS float* b_g2 = b_g1 + 32 * HT;
+        const NRF_LDS float* b_op = b_g2 + 32 * HT;             // output_proj
+        const NRF_LDS float* b_tr = b_op + 32 * HT;             // density trunk
+        Carry<Mode, NT> cy;
         {
             Act x[KT0][NT];
             inputs(w0, w1, x);
-            dense_act<Mode, KT0, HT, NT, true>(pipe, bias + boff, h, x, A); boff += 32 * HT;
+            dense_act_chain<Mode, KT0, HT, NT, true, kCarryNone, kCarryTail>(pipe, b_f1, b_f2, h, x, A, cy);
         }
-        dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
+        dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, b_f2, b_a0, h, A, B, cy);
         {   // attention: Linear(256->64)+ReLU, Linear(64->2), softmax over the pair (lora_dino.py:162-167,184)
             Act a0[HT / 4][NT];
-            dense_act<Mode, HT, HT / 4, NT, true>(pipe, bias + boff, h, B, a0); boff += 8 * HT;
+            dense_act_chain<Mode, HT, HT / 4, NT, true, kCarryTail, kCarryPre>(pipe, b_a0, b_a1, h, B, a0, cy);
             f32x16 lg[NT];
-            dense_head<Mode, HT / 4, NT>(pipe, bias + boff, h, a0, lg); boff += 32;
+            dense_head_chain<Mode, HT / 4, NT, kCarryPre, kCarryPre>(pipe, b_a1, b_g1, h, a0, lg, cy);
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const float d = lg[n][1] - lg[n][0];
@@ -264,20 +273,30 @@ struct NetV3 {
         {
             Act x[KT0][NT];
             inputs(w0, w1, x);
-            dense_act<Mode, KT0, HT, NT, true>(pipe, bias + boff, h, x, A); boff += 32 * HT;
+            dense_act_chain<Mode, KT0, HT, NT, true, kCarryPre, kCarryTail>(pipe, b_g1, b_g2, h, x, A, cy);
         }
-        dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-        dense_act<Mode, HT, HT, NT, false>(pipe, bias + boff, h, B, A); boff += 32 * HT;       // output_proj: no activation
-        for (int p = 0; p < n_layers / 2; ++p) {
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, B, A); boff += 32 * HT;
-        }
-        Carry<Mode, NT> none;
-        if (n_layers & 1) {
-            dense_act<Mode, HT, HT, NT, true>(pipe, bias + boff, h, A, B); boff += 32 * HT;
-            NetV2<Mode, NT, LP>::template tail<kCarryNone>(pipe, bias + boff, h, B, A, dir, out4, none);
+        dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, b_g2, b_op, h, A, B, cy);
+        dense_act_chain<Mode, HT, HT, NT, false, kCarryTail, kCarryTail>(pipe, b_op, b_tr, h, B, A, cy);       // output_proj: no activation
+        int boff = (int)(b_tr - bias);
+        // the first trunk layer completes the un-activated output_proj tile, the others ReLU tiles
+        if (n_layers >= 2) {
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail, false>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, B, A, cy); boff += 32 * HT;
+            for (int p = 1; p < n_layers / 2; ++p) {
+                dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+                dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, B, A, cy); boff += 32 * HT;
+            }
+            if (n_layers & 1) {
+                dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+                NetV2<Mode, NT, LP>::template tail<kCarryTail>(pipe, bias + boff, h, B, A, dir, out4, cy);
+            } else {
+                NetV2<Mode, NT, LP>::template tail<kCarryTail>(pipe, bias + boff, h, A, B, dir, out4, cy);
+            }
+        } else if (n_layers == 1) {
+            dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail, false>(pipe, bias + boff, bias + boff + 32 * HT, h, A, B, cy); boff += 32 * HT;
+            NetV2<Mode, NT, LP>::template tail<kCarryTail>(pipe, bias + boff, h, B, A, dir, out4, cy);
         } else {
-            NetV2<Mode, NT, LP>::template tail<kCarryNone>(pipe, bias + boff, h, A, B, dir, out4, none);
+            NetV2<Mode, NT, LP>::template tail<kCarryTail, false>(pipe, bias + boff, h, A, B, dir, out4, cy);
         }
     }
 };

@@ -184,6 +184,28 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             };
             // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
             auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+#ifdef NRF_ABLATE_BUILD
+                if (P.net.ablate & 16) {      // timing experiment: no encoder (and no compositor below)
+                    // hashed bit patterns in bf16 [0.008, 2): realistic toggling (all-zero operands let the clock rise) at ~1/6 of the encoder's VALU work
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+#pragma unroll
+                        for (int t = 0; t < Net::KT0; ++t) {
+                            i32x4 w0v, w1v;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const unsigned hsh = (unsigned)(tid_now * 2654435761u) + (unsigned)(p * 40503 + (8 * t + q + 4 * n) * 7919);
+                                w0v[q] = (int)(((hsh * 2246822519u) & 0x3FFF3FFFu) | 0x3C003C00u) ^ ((hsh & 1u) << 31);
+                                w1v[q] = (int)(((hsh * 3266489917u) & 0x3FFF3FFFu) | 0x3C003C00u) ^ ((hsh & 2u) << 14);
+                            }
+                            Act e = {};
+                            __builtin_memcpy(&e, &w0v, 16);
+                            __builtin_memcpy((char*)&e + 16, &w1v, 16);
+                            x[t][n] = e;
+                        }
+                    return;
+                }
+#endif
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
                     // depth of this column's sample (columns past the last sample repeat it; their outputs are not used)
@@ -228,6 +250,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             for (int j = 0; j < SPW; ++j) {
                 const int s = p * SPW + j;
                 if (s >= S) break;
+#ifdef NRF_ABLATE_BUILD
+                if (P.net.ablate & 16) { comp.r += out4[0][0] + out4[NT - 1][3]; break; }
+#endif
                 const bool last = (s + 1 == S);
                 float v[4];
                 if (SPW == 1) {

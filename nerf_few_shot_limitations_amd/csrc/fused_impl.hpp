@@ -182,7 +182,12 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                     dt[0][n] = t1[0];
                 }
             };
-            // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass)
+            // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass: the blended feature-map
+            // channels -- 16 DT fp32 registers per operand tile -- are held across the first pass, so that the gather, two rounds of
+            // global loads whose latency a lone wave cannot cover, happens once per sample; the encoder's trig is recomputed)
+            constexpr int kHeld = Net::kDino ? 16 * (Net::KT0 - KT0) : 1;
+            float held[NT][kHeld];
+            bool held_valid = false;
             auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
 #ifdef NRF_ABLATE_BUILD
                 if (P.net.ablate & 16) {      // timing experiment: no encoder (and no compositor below)
@@ -227,13 +232,17 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                     for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                     if constexpr (Net::kDino) {
                         constexpr int DT = Net::KT0 - KT0;
-                        const DinoTaps tp = dino_taps(a.dino, pt);
+                        if (!held_valid) {
+                            const DinoTaps tp = dino_taps(a.dino, pt);
+                            dino_blend<DT>(a.dino.features, tp, h, held[n]);
+                        }
                         Act dt[DT];
-                        dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
+                        dino_scaled_tiles<Mode, DT>(held[n], w1[n], dt);
 #pragma unroll
                         for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
                     }
                 }
+                held_valid = true;
             };
 
             float out4[NT][4];
@@ -450,8 +459,14 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
                 dt[0][n] = t1[0];
             }
         };
+        constexpr int kHeld = Net::kDino ? 16 * (Net::KT0 - KT0) : 1;     // render_kernel: the gathered channels are held across NetV3's first fusion pass
+        float held[NT][kHeld];
+        bool held_valid = false;
         auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
-            if (pipe.skip) return;
+            // (a wave that has run dry encodes its stale -- valid -- state like any other: an early return here made every operand
+            // tile and the held channels values merged across a branch, 300 spilled registers in the V3 build)
+            const bool first = !held_valid;
+            held_valid = true;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const float zc = SQ(n, F_Z);
@@ -465,9 +480,12 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
                 for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                 if constexpr (Net::kDino) {
                     constexpr int DT = Net::KT0 - KT0;
-                    const DinoTaps tp = dino_taps(a.dino, p);
+                    if (first) {
+                        const DinoTaps tp = dino_taps(a.dino, p);
+                        dino_blend<DT>(a.dino.features, tp, h, held[n]);
+                    }
                     Act dt[DT];
-                    dino_tiles<Mode, DT>(a.dino.features, tp, h, w1[n], dt);
+                    dino_scaled_tiles<Mode, DT>(held[n], w1[n], dt);
 #pragma unroll
                     for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
                 }

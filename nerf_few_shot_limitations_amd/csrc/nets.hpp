@@ -337,13 +337,11 @@ __device__ __forceinline__ DinoTaps dino_taps(const DinoT& d, const float p[3]) 
     return t;
 }
 
-// the fetched channels as DT operand tiles for lane half h: register 4g+e of tile t holds channel 32t+8g+4h+e
-template <class Mode, int DT>
-__device__ __forceinline__ void dino_tiles(const float* __restrict__ feat, const DinoTaps& tp, int h, float scale,
-                                           typename Mode::Act (&out)[DT]) {
+// the fetched channels of lane half h, blended in fp32: e[16 t + 4 g + q] = channel 32t + 8g + 4h + q
+template <int DT>
+__device__ __forceinline__ void dino_blend(const float* __restrict__ feat, const DinoTaps& tp, int h, float (&e)[16 * DT]) {
 #pragma unroll
     for (int t = 0; t < DT; ++t) {
-        f32x16 e;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int ch = 32 * t + 8 * g + 4 * h;
@@ -356,10 +354,29 @@ __device__ __forceinline__ void dino_tiles(const float* __restrict__ feat, const
                 }
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[4 * g + q] = acc[q] * scale;
+            for (int q = 0; q < 4; ++q) e[16 * t + 4 * g + q] = acc[q];
         }
-        out[t] = Mode::template to_act<false>(e);
     }
+}
+
+// ... as DT operand tiles, scaled by the fusion gate
+template <class Mode, int DT>
+__device__ __forceinline__ void dino_scaled_tiles(const float (&e)[16 * DT], float scale, typename Mode::Act (&out)[DT]) {
+#pragma unroll
+    for (int t = 0; t < DT; ++t) {
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = e[16 * t + r] * scale;
+        out[t] = Mode::template to_act<false>(v);
+    }
+}
+
+template <class Mode, int DT>
+__device__ __forceinline__ void dino_tiles(const float* __restrict__ feat, const DinoTaps& tp, int h, float scale,
+                                           typename Mode::Act (&out)[DT]) {
+    float e[16 * DT];
+    dino_blend<DT>(feat, tp, h, e);
+    dino_scaled_tiles<Mode, DT>(e, scale, out);
 }
 
 }  // namespace nrf

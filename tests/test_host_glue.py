@@ -91,3 +91,15 @@ def test_ssim_against_an_independent_restatement():
     assert abs(N.ssim(torch.from_numpy(a), torch.from_numpy(b)) - ref_ssim(a, b, dr, True)) < 2e-6
     assert abs(N.ssim(torch.from_numpy(a), torch.from_numpy(b), data_range=1.0, crop_border=False) - ref_ssim(a, b, 1.0, False)) < 2e-6
     assert abs(N.ssim(torch.from_numpy(a).permute(2, 0, 1), torch.from_numpy(b).permute(2, 0, 1)) - ref_ssim(a, b, dr, True)) < 2e-6
+
+
+def test_entry_points_and_tools_compile():
+    """The driver imports __graft_entry__ and runs bench.py as scripts: a syntax error there is invisible to every other test."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in [os.path.join(root, "__graft_entry__.py"), os.path.join(root, "bench.py")] + sorted(glob.glob(os.path.join(root, "tools", "*.py"))):
+        py_compile.compile(path, doraise=True)
+    import importlib
+    entry = importlib.import_module("__graft_entry__")
+    assert callable(entry.build) and callable(entry.smoke)

@@ -1,10 +1,11 @@
 // fused_impl.hpp -- the fused sample -> encode -> MLP -> composite renderer and the staged MLP
 // forward, hand-written for gfx950 (CDNA4).  See mlp_core.hpp for the MFMA / weight-stream design.
 //
-// Work mapping of the renderer: a persistent workgroup (8 waves, two per SIMD -- 4 in the fp32 / split-f16 modes --, 1 workgroup
-// per CU because of its ~147 KiB of LDS) walks ray tiles.  Inside a wave LANE <-> RAY: the wave marches its rays front to back,
-// so a ray's transmittance / colour / depth accumulators belong to ONE lane (parked in LDS between passes) and compositing
-// never crosses lanes.  Early ray termination (ert_eps > 0) runs on render_queue_kernel: lanes refill from a ray queue.
+// Work mapping of the renderer: a persistent workgroup (4 waves, one per SIMD: 64 sample columns each in the 16-bit modes, 32 in
+// the fp32 / split-f16 modes -- "Workgroup geometry" below; 1 workgroup per CU because of its ~147 KiB of LDS) walks ray tiles.
+// Inside a wave LANE <-> RAY: the wave marches its rays front to back, so a ray's transmittance / colour / depth accumulators
+// belong to ONE lane (parked in LDS between passes) and compositing never crosses lanes.  Early ray termination (ert_eps > 0)
+// runs on render_queue_kernel: columns refill from a ray queue.
 #pragma once
 #include <atomic>
 #include <cstdlib>

@@ -215,7 +215,7 @@ struct Pipe {
 // ---------------------------------------------------------------------------
 struct ModeBF16 {
     static constexpr int SUB = 2;            // fragments per (m-tile, k-tile)
-    static constexpr bool kPinned = false;   // at two waves per SIMD (NT = 1) the waves cover each other: hipcc's own schedule is as fast (pinned: +0.5 %)
+    static constexpr bool kPinned = false;   // pinned by geometry (pinned_walk): the inference kernels run NT = 2; the training kernels (NT = 1, two waves per SIMD) keep dense()
     static constexpr int TRIG = 1;           // v_sin on exactly reduced turns: error far below bf16 resolution (nets.hpp:encode3)
     static constexpr bool FAST_EXP = true;   // v_exp based exp/sigmoid in the compositor
     typedef bf16x8 frag_t;

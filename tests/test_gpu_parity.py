@@ -445,6 +445,35 @@ def test_camera_mode_equals_explicit_rays_bitwise(N):
         assert torch.equal(a["rgb"], rgb) and torch.equal(a["depth"], depth)
 
 
+@pytest.mark.parametrize("net,mode", [("v1", "bf16"), ("v1", "f16"), ("v1", "f16x3"), ("v2", "bf16"), ("v2", "f32"), ("v3", "bf16"), ("v3", "f16x3")])
+def test_ray_batches_split_anywhere_bitwise(N, net, mode):
+    """A ray's result must not depend on where in a launch it sits: which wave, which of a wave's 32 / 64 sample columns, which
+    samples-per-pass split the launcher picked (fused_impl.hpp: pick_spw_log2), plain or ray-queue kernel.  Ragged counts around
+    the wave (64) and workgroup (256) sizes, rendered whole and in pieces."""
+    S = 12
+    H, W = 19, 31                                       # 589 rays
+    c2w = T(O.LEGO_LIKE_C2W)
+    ro, rd = N.get_rays(H, W, O.focal_for(W), c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    kw = {}
+    if net == "v1":
+        m, _ = model_v1(N, "solid", mode)
+    elif net == "v2":
+        m, _ = model_v2(N, "solid", mode)
+    else:
+        m, _ = model_v3(N, "solid", mode)
+        kw["dino"] = dict(features=dino_map(), pose=c2w, focal=O.focal_for(W), H=H, W=W)
+    for eps in (0.0, 1e-30):                            # 1e-30: the ray-queue kernel, nothing terminates
+        whole = N.render_rays(m, ro, rd, 2.0, 6.0, S, ert_eps=eps, **kw)
+        for cuts in ((1,), (63, 64, 65), (255, 257, 300), (31, 333, 588)):
+            edges = (0,) + cuts + (ro.shape[0],)
+            parts = [N.render_rays(m, ro[a:b], rd[a:b], 2.0, 6.0, S, ert_eps=eps, **kw) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+            for key in ("rgb", "depth", "weights"):
+                assert torch.equal(torch.cat([q[key] for q in parts]), whole[key]), (net, mode, eps, cuts, key)
+    plain = N.render_rays(m, ro, rd, 2.0, 6.0, S, **kw)
+    assert torch.equal(plain["rgb"], whole["rgb"]) and torch.equal(plain["depth"], whole["depth"])       # queue kernel == tile kernel
+
+
 def test_tile_shards_reassemble_bitwise(N):
     """Pixel-tile sharding contract: rendering ray ranges separately and
     concatenating must reproduce the single-launch frame bit for bit."""

@@ -5,17 +5,18 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 #define LDS __attribute__((address_space(3)))
 
-template <int SHAPE, int NS>   // SHAPE 32: 32x32x16, NS independent column tiles; SHAPE 16: 16x16x32
-__global__ void __launch_bounds__(512) probe(const bf16x8* __restrict__ w, float* out, int iters) {
+template <int SHAPE, int NS, int THREADS = 512>   // SHAPE 32: 32x32x16, NS independent column tiles; SHAPE 16: 16x16x32; THREADS 512 = two waves per SIMD, 256 = one
+__global__ void __launch_bounds__(THREADS) probe(const bf16x8* __restrict__ w, float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LDS bf16x8* lds = (LDS bf16x8*)smem;
-    for (int i = threadIdx.x; i < 128 * 64; i += 512) lds[i] = w[i];          // 128 fragments of 1 KiB
+    for (int i = threadIdx.x; i < 128 * 64; i += THREADS) lds[i] = w[i];          // 128 fragments of 1 KiB
     __syncthreads();
     const int lane = threadIdx.x & 63;
     bf16x8 b[8];
@@ -33,7 +34,7 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* __restrict__ w, float
             }
         }
         float s = 0; for (int n = 0; n < NS; ++n) for (int r = 0; r < 16; ++r) s += acc[n][r];
-        out[blockIdx.x * 512 + threadIdx.x] = s;
+        out[blockIdx.x * THREADS + threadIdx.x] = s;
     } else {
         f32x4 acc[2][NS];
         for (int hh = 0; hh < 2; ++hh) for (int n = 0; n < NS; ++n) for (int r = 0; r < 4; ++r) acc[hh][n][r] = 0.f;
@@ -47,21 +48,21 @@ __global__ void __launch_bounds__(512) probe(const bf16x8* __restrict__ w, float
             }
         }
         float s = 0; for (int hh = 0; hh < 2; ++hh) for (int n = 0; n < NS; ++n) for (int r = 0; r < 4; ++r) s += acc[hh][n][r];
-        out[blockIdx.x * 512 + threadIdx.x] = s;
+        out[blockIdx.x * THREADS + threadIdx.x] = s;
     }
 }
 
-template <int SHAPE, int NS>
+template <int SHAPE, int NS, int THREADS = 512>
 double run(const bf16x8* w, float* out, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    hipFuncSetAttribute((const void*)probe<SHAPE, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    probe<SHAPE, NS><<<256, 512, 128 * 1024>>>(w, out, iters / 4);
+    hipFuncSetAttribute((const void*)probe<SHAPE, NS, THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    probe<SHAPE, NS, THREADS><<<256, THREADS, 128 * 1024>>>(w, out, iters / 4);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    probe<SHAPE, NS><<<256, 512, 128 * 1024>>>(w, out, iters);
+    probe<SHAPE, NS, THREADS><<<256, THREADS, 128 * 1024>>>(w, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
-    const double flops = 256.0 * 8 * iters * 128 * NS * (SHAPE == 32 ? 32768.0 : 16384.0);
+    const double flops = 256.0 * (THREADS / 64) * iters * 128 * NS * (SHAPE == 32 ? 32768.0 : 16384.0);
     return flops / (ms * 1e-3) / 1e12;
 }
 
@@ -78,6 +79,10 @@ int main() {
         printf("16x16x32 NS=2 (same LDS bytes/FLOP): %.0f TFLOP/s\n", run<16, 2>(w, out, iters));
         printf("32x32x16 NS=2 (half LDS bytes/FLOP): %.0f TFLOP/s\n", run<32, 2>(w, out, iters / 2));
         printf("16x16x32 NS=4 (half LDS bytes/FLOP): %.0f TFLOP/s\n", run<16, 4>(w, out, iters / 2));
+        // the round-2 geometry: one wave per SIMD, 64 columns per wave
+        printf("one wave/SIMD 32x32x16 NS=2: %.0f TFLOP/s\n", run<32, 2, 256>(w, out, iters));
+        printf("one wave/SIMD 16x16x32 NS=4: %.0f TFLOP/s\n", run<16, 4, 256>(w, out, iters));
+        printf("one wave/SIMD 32x32x16 NS=4 (quarter LDS bytes/FLOP): %.0f TFLOP/s\n", run<32, 4, 256>(w, out, iters / 2));
     }
     return 0;
 }

@@ -31,21 +31,42 @@ import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# The arithmetic mode of the headline number: the fastest mode whose PSNR stays within 0.01 dB of the fp32 render on a TRAINED
+# field and on the solid-scene band (BASELINE.json's PSNR bar; tools/trained_scene.py, tests/test_gpu_trained_scene.py assert it).
+# bf16 (same MFMA rate, 8 mantissa bits) misses that bar by 10-30x and stays available as --mode bf16.
+HEADLINE_MODE = "f16"
+
 PEAK_TFLOPS = {"bf16": 2500.0, "f16": 2500.0, "f32": 157.3, "f16x3": 2500.0}      # /opt/skills/guides/MI355X_MICROARCH.md, dense
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (torch.distributed.run, one
+    per GPU) before this process has touched a GPU or imported torch, pass rank 0's JSON line through (the children inherit
+    stdout) and exit with their status.  Nothing is ever exec'd from a process that initialised HIP."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def training_line(N, args, dev):
     """SURVEY.md section 8 row f1, reported next to the render metric (not part of `value`): one optimisation step of the
     reference's loop (train.py:280-288 / train_minimal.py:102-123: render a ray batch, mse on rgb, backward, Adam) at the
     reference's own batch (baseline.yaml:32-34: 2048 rays x 32 samples), random-init weights, through training.FusedStep."""
+    import torch
     from nerf_few_shot_limitations_amd.training import FusedStep
     R, S = 2048, 32
     mode = args.mode if args.mode != "f16x3" else "f32"
@@ -83,7 +104,8 @@ def training_line(N, args, dev):
             "loss_first": round(first, 6), "loss_last": round(loss.item(), 6)}
 
 
-def main():
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -91,7 +113,7 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--samples", type=int, default=64)
-    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32", "f16x3"])
+    ap.add_argument("--mode", default=HEADLINE_MODE, choices=["bf16", "f16", "f32", "f16x3"])
     ap.add_argument("--net", default="v1", choices=["v1", "v2", "v3"])
     ap.add_argument("--scene", default="solid", choices=["fog", "solid", "smooth"])
     ap.add_argument("--ert", type=float, default=0.0)
@@ -103,19 +125,23 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the parity_mode / ert legs (N=1 only)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: do not overlap the all_gather of a step with the next step's render")
     ap.add_argument("--cpu-rows", type=int, default=16, help="rows of the frame the CPU baseline renders (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--no-trained-scene", action="store_true", help="skip parity.trained_scene (train a field on a generated scene, PSNR delta of every mode; N=1 only)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a box with ONE GPU: every rank on cuda:0, tiles exchanged over gloo through host memory (RCCL refuses two ranks on "
+                         "one card).  Exercises the launcher, the tile dealing and the gather; its numbers are not multi-GPU numbers")
+    args = ap.parse_args(argv)
 
-    # one rank per GPU, decided from the launcher's environment BEFORE anything touches a device
+    # one rank per GPU, decided from the launcher's environment BEFORE anything touches a device (torch is not even imported yet)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    # rehearsal knobs (one-GPU box): NERF_BENCH_FORCE_DEVICE=0 puts every rank on one card, NERF_BENCH_BACKEND=gloo
-    # exchanges through host memory; the driver's multi-GPU runs use neither (one rank per GPU, RCCL).
-    force = os.environ.get("NERF_BENCH_FORCE_DEVICE")
-    dev_index = int(force) if force is not None else local_rank
-    backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or with no launcher at all")
+    import torch
+    dev_index = 0 if args.rehearse else local_rank
+    backend = "gloo" if args.rehearse else "nccl"
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
@@ -236,24 +262,19 @@ def main():
             dt = float(t.item())
         kms = sum(a.elapsed_time(b) for a, b in kev) / max(len(kev), 1)
         gms = sum(a.elapsed_time(b) for a, b in gev) / max(len(gev), 1) if (world > 1 and len(jobs) == 1) else None
-        return dt, kms, gms, jobs[0].rays_per_launch
+        return dt, kms, gms, jobs[0].rays_per_step, jobs[0].launches_per_step
 
     views_main = world if args.scaling == "weak" else 1
     overlap = world > 1 and backend == "nccl" and not args.no_overlap
-    try:
-        dt, kernel_ms, gather_ms, rays_per_launch = run(views_main, args.steps, args.warmup, overlap)
-    except Exception as e:                                  # the serial exchange is the conservative form: fall back to it
-        if not overlap:
-            raise
-        print(f"[bench] rank {rank}: overlapped gather failed ({type(e).__name__}: {e}); repeating with --no-overlap", file=sys.stderr, flush=True)
-        overlap = False
-        dt, kernel_ms, gather_ms, rays_per_launch = run(views_main, args.steps, args.warmup, overlap)
+    # no automatic fall-back to the serial exchange: a rank that switched protocol on its own would leave the others inside
+    # mismatched collectives (a hang instead of an error).  An RCCL failure surfaces; --no-overlap selects the serial form.
+    dt, kernel_ms, gather_ms, rays_per_step_rank, launches_per_step = run(views_main, args.steps, args.warmup, overlap)
     print(f"[bench] rank {rank}: timed region done", file=sys.stderr, flush=True)
     if world > 1 and gather_ms is None and args.other_steps > 0:
         # the exchange on its own: a few steps with the all_gather NOT overlapped, timed with events around it
-        _, _, gather_ms, _ = run(views_main, min(args.other_steps, 5), 1, False)
+        _, _, gather_ms, _, _ = run(views_main, min(args.other_steps, 5), 1, False)
 
-    samples_per_launch = rays_per_launch * S
+    samples_per_launch = rays_per_step_rank * S                   # what this rank's launch(es) of one step march: kernel_ms spans exactly them
     samples_per_step = views_main * H * W * S                     # all ranks together
     value = samples_per_step * args.steps / dt / 1e6
     achieved = samples_per_launch * flops_per_sample / (kernel_ms * 1e-3) / 1e12
@@ -278,23 +299,27 @@ def main():
         "dtype": args.mode, "data": "synthetic",
         "config": {"workload": f"{H}x{W} camera frame x {S} samples/ray, NeRFMLP {args.net} 8x256, scene {args.scene}, "
                                f"{views_main} view(s)/step, {tile_rows}-row pixel tiles dealt round-robin over {world} GPU(s), one launch + one all_gather per step",
-                   "rays_per_gpu_per_step": rays_per_launch, "samples_per_ray": S, "ert_eps": args.ert,
+                   "rays_per_gpu_per_step": rays_per_step_rank, "samples_per_ray": S, "ert_eps": args.ert,
                    "flops_per_sample": flops_per_sample, "parallelism": f"pixel-tile x{world}",
-                   "gather": ("all_gather of step i overlapped with the render of step i+1 (two gather buffers)" if overlap else
-                              ("one all_gather between renders" if world > 1 else "none (one GPU)"))},
+                   "gather": ("all_gather of step i overlapped with the render of step i+1 (two gather buffers); no fallback fired (there is none: a failure raises)"
+                              if overlap else (("one all_gather between renders" + (" over gloo through host memory (rehearsal)" if args.rehearse else ""))
+                                               if world > 1 else "none (one GPU)"))},
         "gather_ms": None if gather_ms is None else round(gather_ms, 4),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_TFLOPS[args.mode], "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_TFLOPS[args.mode], 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": args.steps},
+                     "kernel": "render_kernel", "kernel_ms": round(kernel_ms, 4), "launches_timed": args.steps * launches_per_step,
+                     "launches_per_step": launches_per_step},
+        "distributed": {"world_size": world if dist is None else dist.get_world_size(), "backend": "none (one process)" if dist is None else dist.get_backend(),
+                        "rehearsal_on_one_gpu": bool(args.rehearse), "launcher": "torch.distributed.run (self-launched when no WORLD_SIZE is set)"},
     }
 
     # the other scaling mode, a few steps (every rank takes part)
     if args.other_steps > 0 and world > 1:
         other = "strong" if args.scaling == "weak" else "weak"
         views_o = 1 if other == "strong" else world
-        dto, kmo, gmo, rays_o = run(views_o, args.other_steps, 2, overlap)
+        dto, kmo, gmo, rays_o, _ = run(views_o, args.other_steps, 2, overlap)
         if gmo is None:
-            _, _, gmo, _ = run(views_o, min(args.other_steps, 5), 1, False)
+            _, _, gmo, _, _ = run(views_o, min(args.other_steps, 5), 1, False)
         out[f"{other}_scaling"] = {
             "workload": f"{views_o} view(s) of {H}x{W}x{S} per step cut over {world} GPU(s)", "steps": args.other_steps,
             "value": round(views_o * H * W * S * args.other_steps / dto / 1e6, 2), "unit": "M ray-samples/s",
@@ -338,6 +363,17 @@ def main():
                          "meets_1e-4": bool(float((rgb_m.cpu() - ref["rgb"]).abs().max()) <= 1e-4 and float((depth_m.cpu() - ref["depth"]).abs().max()) <= 1e-4),
                          "meets_0.01dB": bool(abs(O.psnr(rgb_m.cpu(), gt) - ps_ref) <= 0.01)}
         out["parity"] = par
+        if not args.no_trained_scene and args.net in ("v1", "v2"):
+            # PSNR delta of every mode on a TRAINED field (tools/trained_scene.py): a generated Blender-format scene, baseline.yaml's
+            # schedule through the HIP training path, the same weights rendered in every mode against the ground-truth images
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import trained_scene
+            print("[bench] parity.trained_scene: training a field on the generated scene ...", file=sys.stderr, flush=True)
+            par["trained_scene"] = trained_scene.run(net=args.net, train_mode="bf16")     # trained in bf16 (its exponent range suits the unscaled gradients); every mode renders the SAME weights
+            par["headline_mode"] = {"mode": args.mode,
+                                    "meets_0.01dB_on_band": par[args.mode]["meets_0.01dB"],
+                                    "meets_0.01dB_on_trained_scene": bool(par["trained_scene"]["train"][args.mode]["meets_0.01dB"]
+                                                                          and par["trained_scene"]["test"][args.mode]["meets_0.01dB"])}
 
     if single and not args.no_extras:
         def time_frames(mdl, mode, reps, **kw):
@@ -356,14 +392,14 @@ def main():
 
         # the parity-grade fast mode next to the other modes, same frame, credited 1x the algorithmic FLOPs
         pm = {}
-        for mode, reps in (("f16x3", 5), ("f16", 10), ("f32", 3)):
+        for mode, reps in (("f16x3", 5), ("f16", 10), ("bf16", 10), ("f32", 3)):
             ms, _ = time_frames(model, mode, reps)
             tf = H * W * S * flops_per_sample / (ms * 1e-3) / 1e12
             pm[mode] = {"ms_per_frame": round(ms, 3), "M_ray_samples_per_s": round(H * W * S / ms / 1e3, 1), "TFLOP_per_s_credited": round(tf, 1),
                         "frac_of_2.5PF": round(tf / 2500.0, 4)}
         pm["mode"] = "f16x3"
         pm["note"] = ("f16x3 = split f16 (hi+lo operands, 3 MFMAs per product at the 32x32x16 rate): meets the 1e-4 abs and 0.01 dB bars (see parity); "
-                      "f16 meets the 0.01 dB bar only; bf16 (the headline) neither; f32 = exact fp32 MFMA at 1/16 rate")
+                      "f16 (the headline) meets the 0.01 dB bar only; bf16 neither; f32 = exact fp32 MFMA at 1/16 rate")
         out["parity_mode"] = pm
         # early ray termination where it can act: the coherent opaque "smooth" scene
         eps = 1e-2

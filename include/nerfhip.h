@@ -43,8 +43,10 @@ extern "C" {
 #define NRF_NET_V3 3  /* src/models/nerf_mlp.py:86-158  NeRFWithDINO: + lora_dino.py:146-193 NeRFDINOFusion */
 
 /* arithmetic of the MLP contraction (accumulation is always fp32) */
-#define NRF_MMA_BF16 0  /* v_mfma_f32_32x32x16_bf16: weights + activations rounded to bf16 (throughput mode) */
-#define NRF_MMA_F16  1  /* v_mfma_f32_32x32x16_f16 : same rate, 3 more mantissa bits                          */
+#define NRF_MMA_BF16 0  /* v_mfma_f32_32x32x16_bf16: weights + activations rounded to bf16 (8 mantissa bits: misses the 0.01 dB PSNR bar) */
+#define NRF_MMA_F16  1  /* v_mfma_f32_32x32x16_f16 : same rate, 3 more mantissa bits: the throughput mode whose PSNR stays within 0.01 dB of
+                           the fp32 render (bench.py's default).  f16-typed weight streams (this mode and NRF_MMA_F16X3) saturate at
+                           +-65504 instead of overflowing to inf                                                                     */
 #define NRF_MMA_F32  2  /* v_mfma_f32_32x32x2_f32  : exact fp32 fma chain (parity mode, 1/16 rate)           */
 #define NRF_MMA_F16X3 3 /* split f16: x = hi + lo (22 bits), W_hi X_hi + W_hi X_lo + W_lo X_hi as three 32x32x16 MFMAs: fp32-class
                            results (meets the 1e-4 bar of the fp32 mode) at up to 1/3 of the 16-bit rate.  Inference entry
@@ -102,8 +104,9 @@ typedef struct nrf_render_opts {
     int32_t  white_bkgd;     /* nerf_mlp.py:209-212                                                   */
     int32_t  mma_mode;       /* NRF_MMA_*                                                             */
     const nrf_dino* dino;    /* V3 only (host struct, copied at launch)                               */
-    int32_t  out_rgbd;       /* 1: `rgb` points at (R,4) rows [r,g,b,depth] written with one 16-byte store per ray (16-byte aligned)
-                                and `depth` is ignored (may be NULL) -- the layout of the multi-GPU gather buffer; 0: (R,3) + (R) */
+    int32_t  out_rgbd;       /* 1: `rgb` points at (R,4) rows [r,g,b,depth] written with one 16-byte store per ray and `depth` is ignored
+                                (may be NULL) -- the layout of the multi-GPU gather buffer; `rgb` must be 16-byte aligned, a
+                                misaligned pointer is refused with NRF_EINVAL; 0: (R,3) + (R) */
 } nrf_render_opts;
 
 /* ---- model handle -------------------------------------------------------- */
@@ -180,7 +183,10 @@ int nrf_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
                   const float* z_vals, const float* rays_d, int64_t n_rays, int n_samples, int white_bkgd,
                   float* out_rgb, float* out_depth, float* out_weights, void* stream);
 /* ray_utils.py:86-143 (intent; the reference function raises):
- * z_vals, weights (R,S) -> samples (R,Ni) and sorted union (R,S+Ni); u (R,Ni) or NULL -> linspace(0,1,Ni). */
+ * z_vals, weights (R,S) -> samples (R,Ni) and sorted union (R,S+Ni); u (R,Ni) or NULL -> linspace(0,1,Ni).
+ * The two reductions (:107-109) follow PyTorch's CPU kernels -- weights.sum in ATen's cascade order (8-float vectors),
+ * torch.cumsum accumulated in double and rounded per knot -- so the `denom < 1e-5` guard (:131) takes the same branch as the
+ * reference's fp32 CPU run would. */
 int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance,
                    const float* u, float* samples, float* z_union, void* stream);
 /* ray_utils.py:176-210 + dino_feature_model.py:114-148: points (N,3) -> features (N,C); xy (N,2) may be NULL. */

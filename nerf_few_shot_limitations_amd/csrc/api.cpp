@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <string>
@@ -217,6 +218,13 @@ int check_opts(const nrf_render_opts* o) {
     return NRF_OK;
 }
 
+// out_rgbd rows are written with one 16-byte store per ray: refuse a misaligned base before anything else is looked at (a C caller
+// passing a float-aligned sub-view would otherwise get a GPU memory fault instead of an error code)
+bool rgbd_misaligned(const nrf_render_opts* o, const float* rgb) {
+    return o && o->out_rgbd && rgb && (reinterpret_cast<uintptr_t>(rgb) & 15u) != 0;
+}
+const char* const kRgbdAlign = "out_rgbd: rgb must be 16-byte aligned ((R,4) rows written with one 16-byte store per ray)";
+
 void fill_common(nrf::RenderArgs& a, const nrf_render_opts* o, float* rgb, float* depth, float* weights, float* z_vals) {
     a.near = o->near; a.far = o->far; a.n_samples = o->n_samples; a.lindisp = o->lindisp; a.perturb = o->perturb;
     a.t_rand = o->perturb ? o->t_rand : nullptr; a.z_ladder = o->z_ladder; a.z_in = o->z_in; a.seed = o->rng_seed;
@@ -306,6 +314,7 @@ int64_t nrf_model_flops_per_sample(const nrf_model* m) { return m ? m->plan.flop
 
 int nrf_render_rays(const nrf_model* m, const float* rays_o, const float* rays_d, int64_t n_rays, const nrf_render_opts* opts,
                     float* rgb, float* depth, float* weights, float* z_vals, void* stream) {
+    if (rgbd_misaligned(opts, rgb)) return fail(NRF_EINVAL, kRgbdAlign);
     if (!m) return fail(NRF_EINVAL, "model is NULL");
     if (n_rays < 0) return fail(NRF_EINVAL, "n_rays < 0");
     if (n_rays == 0) return NRF_OK;
@@ -327,6 +336,7 @@ int nrf_render_rays(const nrf_model* m, const float* rays_o, const float* rays_d
 
 int nrf_render_camera(const nrf_model* m, int H, int W, float focal, const float c2w[12], int64_t ray_begin, int64_t ray_end,
                       const nrf_render_opts* opts, float* rgb, float* depth, float* weights, float* z_vals, void* stream) {
+    if (rgbd_misaligned(opts, rgb)) return fail(NRF_EINVAL, kRgbdAlign);
     if (!m) return fail(NRF_EINVAL, "model is NULL");
     if (H < 1 || W < 1 || !(focal > 0.0f) || !c2w) return fail(NRF_EINVAL, "bad camera");
     if (ray_begin < 0 || ray_end < ray_begin || ray_end > (int64_t)H * W) return fail(NRF_EINVAL, "ray range outside the image");
@@ -349,6 +359,7 @@ int nrf_render_camera(const nrf_model* m, int H, int W, float focal, const float
 int nrf_render_cameras_tiles(const nrf_model* m, int H, int W, float focal, const float* c2w, int n_cams, int64_t tile_rays,
                              int64_t first_tile, int64_t tile_step, int64_t n_tiles, const nrf_render_opts* opts, float* rgb, float* depth,
                              float* weights, float* z_vals, void* stream) {
+    if (rgbd_misaligned(opts, rgb)) return fail(NRF_EINVAL, kRgbdAlign);
     if (!m) return fail(NRF_EINVAL, "model is NULL");
     if (H < 1 || W < 1 || !(focal > 0.0f) || !c2w) return fail(NRF_EINVAL, "bad camera");
     if (n_cams < 1 || n_cams > nrf::kMaxCams) return fail(NRF_EINVAL, "n_cams must be in 1..8 per call");

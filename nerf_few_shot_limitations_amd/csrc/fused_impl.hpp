@@ -52,6 +52,14 @@ struct ForwardKArgs {
 template <bool FAST>
 __device__ __forceinline__ float sigmoid_sel(float x) { return FAST ? sigmoid_fast(x) : sigmoid_precise(x); }
 
+// One of two register values by a (lane-dependent or uniform) flag, as a v_cndmask: left to itself LLVM turns
+// `flag ? out4[1][k] : out4[0][k]` into a dynamically indexed load from a STACK copy of out4 (48 bytes of scratch per lane in the
+// V2 / V3 renderers: VMEM traffic at the end of every pass, in front of the LDS-DMA queue)
+__device__ __forceinline__ float pick_reg(float lo, float hi, bool take_hi) {
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    return take_hi ? hi : lo;
+}
+
 __device__ __forceinline__ void load_bias_table(NRF_LDS float* bias, const float* src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) bias[i] = src[i];
     __syncthreads();
@@ -186,10 +194,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             // first-layer operand tiles of this step's samples (re-invoked by NetV3 for its second fusion pass: the blended feature-map
             // channels -- 16 DT fp32 registers per operand tile -- are held across the first pass, so that the gather, two rounds of
             // global loads whose latency a lone wave cannot cover, happens once per sample; the encoder's trig is recomputed)
-            constexpr int kHeld = Net::kDino ? 16 * (Net::KT0 - KT0) : 1;
-            float held[NT][kHeld];
-            bool held_valid = false;
-            auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+            DinoHeld<Mode, Net::kDino ? Net::KT0 - KT0 : 1> held[NT];
+            auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT], auto pass_) {
+                constexpr int PASS = decltype(pass_)::value;
 #ifdef NRF_ABLATE_BUILD
                 if (P.net.ablate & 16) {      // timing experiment: no encoder (and no compositor below)
                     // hashed bit patterns in bf16 [0.008, 2): realistic toggling (all-zero operands let the clock rise) at ~1/6 of the encoder's VALU work
@@ -233,17 +240,13 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                     for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                     if constexpr (Net::kDino) {
                         constexpr int DT = Net::KT0 - KT0;
-                        if (!held_valid) {
-                            const DinoTaps tp = dino_taps(a.dino, pt);
-                            dino_blend<DT>(a.dino.features, tp, h, held[n]);
-                        }
+                        if constexpr (PASS == 0) held[n].gather(a.dino.features, dino_taps(a.dino, pt), h);
                         Act dt[DT];
-                        dino_scaled_tiles<Mode, DT>(held[n], w1[n], dt);
+                        held[n].template tiles<PASS>(w1[n], dt);
 #pragma unroll
                         for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
                     }
                 }
-                held_valid = true;
             };
 
             float out4[NT][4];
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                 if (SPW == 1) {
                     // NT == 2: lane L owns column L = tile h, column c -- and holds that tile's head rows itself
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = (NT == 2 && h) ? out4[NT - 1][k] : out4[0][k];
+                    for (int k = 0; k < 4; ++k) v[k] = NT == 2 ? pick_reg(out4[0][k], out4[NT - 1][k], h != 0) : out4[0][k];
                 } else if (j == 0) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = out4[0][k];
@@ -280,7 +283,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                     const int src = ((lane & 32) | (qj & 31)) << 2;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, upper ? out4[NT - 1][k] : out4[0][k])));
+                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, NT == 2 ? pick_reg(out4[0][k], out4[NT - 1][k], upper) : out4[0][k])));
                 }
                 const float zn = last ? 0.0f : z_ray(rid, s + 1);
                 const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zo), norm);
@@ -460,14 +463,11 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
                 dt[0][n] = t1[0];
             }
         };
-        constexpr int kHeld = Net::kDino ? 16 * (Net::KT0 - KT0) : 1;     // render_kernel: the gathered channels are held across NetV3's first fusion pass
-        float held[NT][kHeld];
-        bool held_valid = false;
-        auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+        DinoHeld<Mode, Net::kDino ? Net::KT0 - KT0 : 1> held[NT];        // render_kernel: the gathered channels are held across NetV3's first fusion pass
+        auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT], auto pass_) {
             // (a wave that has run dry encodes its stale -- valid -- state like any other: an early return here made every operand
             // tile and the held channels values merged across a branch, 300 spilled registers in the V3 build)
-            const bool first = !held_valid;
-            held_valid = true;
+            constexpr int PASS = decltype(pass_)::value;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 const float zc = SQ(n, F_Z);
@@ -481,12 +481,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
                 for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                 if constexpr (Net::kDino) {
                     constexpr int DT = Net::KT0 - KT0;
-                    if (first) {
-                        const DinoTaps tp = dino_taps(a.dino, p);
-                        dino_blend<DT>(a.dino.features, tp, h, held[n]);
-                    }
+                    if constexpr (PASS == 0) held[n].gather(a.dino.features, dino_taps(a.dino, p), h);
                     Act dt[DT];
-                    dino_scaled_tiles<Mode, DT>(held[n], w1[n], dt);
+                    held[n].template tiles<PASS>(w1[n], dt);
 #pragma unroll
                     for (int t = 0; t < DT; ++t) x[KT0 + t][n] = dt[t];
                 }
@@ -505,7 +502,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
             comp.T = ST(F_T); comp.r = ST(F_R); comp.g = ST(F_G); comp.b = ST(F_B); comp.depth = ST(F_DEPTH); comp.acc = ST(F_ACC);
             float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (NT == 2 && h) ? out4[NT - 1][k] : out4[0][k];
+            for (int k = 0; k < 4; ++k) v[k] = NT == 2 ? pick_reg(out4[0][k], out4[NT - 1][k], h != 0) : out4[0][k];
             const float w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]),
                                                               sigmoid_sel<Mode::FAST_EXP>(v[1]), sigmoid_sel<Mode::FAST_EXP>(v[2]), zc, dist);
             const int64_t rr = ray;
@@ -601,7 +598,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
                 }
             }
         };
-        auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT]) {
+        auto inputs = [&](const float (&w0)[NT], const float (&w1)[NT], Act (&x)[Net::KT0][NT], auto) {
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 if constexpr (Net::kNeedsDir) {
@@ -652,7 +649,7 @@ __global__ void __launch_bounds__(WAVES * 64) forward_kernel(const ForwardKArgs 
         if (owner && own_raw < P.n) {
             float v[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = (own == 0) ? out4[0][k] : out4[NT - 1][k];
+            for (int k = 0; k < 4; ++k) v[k] = NT == 2 ? pick_reg(out4[0][k], out4[NT - 1][k], own != 0) : out4[0][k];
             const float r = sigmoid_sel<Mode::FAST_EXP>(v[0]), g = sigmoid_sel<Mode::FAST_EXP>(v[1]), b = sigmoid_sel<Mode::FAST_EXP>(v[2]);
             if constexpr (Net::kNeedsDir) {
                 P.rgb[own_raw * 3 + 0] = r; P.rgb[own_raw * 3 + 1] = g; P.rgb[own_raw * 3 + 2] = b;

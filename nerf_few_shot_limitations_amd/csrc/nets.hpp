@@ -101,7 +101,7 @@ struct NetV1 {
     typedef typename Mode::Act Act;
 
     static constexpr bool kDino = false;
-    // `inputs(w0, w1, x)` fills the first layer's operand tiles (the encoder lives with the caller: fused
+    // `inputs(w0, w1, x, pass)` fills the first layer's operand tiles (the encoder lives with the caller: fused
     // renderer = from the ray, staged forward = from memory); w0/w1 are only meaningful for NetV3
     template <class P, class Inputs, class Dirs>
     __device__ static __forceinline__ void eval(P& pipe, const NRF_LDS float* bias, int h, int n_layers,
@@ -115,7 +115,7 @@ struct NetV1 {
             float one[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) one[n] = 1.0f;
-            inputs(one, one, enc);
+            inputs(one, one, enc, std::integral_constant<int, 0>{});
             dense_act_chain<Mode, KT0, HT, NT, true, kCarryNone, kCarryTail>(pipe, bias, bias + 32 * HT, h, enc, A, cy);
         }
         int boff = 32 * HT;
@@ -200,7 +200,7 @@ struct NetV2 {
             float one[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n) one[n] = 1.0f;
-            inputs(one, one, enc);
+            inputs(one, one, enc, std::integral_constant<int, 0>{});
             dense_act_chain<Mode, KT0, HT, NT, true, kCarryNone, kCarryTail>(pipe, bias, bias + 32 * HT, h, enc, A, cy);
         }
         int boff = 32 * HT;
@@ -254,7 +254,7 @@ struct NetV3 {
         Carry<Mode, NT> cy;
         {
             Act x[KT0][NT];
-            inputs(w0, w1, x);
+            inputs(w0, w1, x, std::integral_constant<int, 0>{});
             dense_act_chain<Mode, KT0, HT, NT, true, kCarryNone, kCarryTail>(pipe, b_f1, b_f2, h, x, A, cy);
         }
         dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, b_f2, b_a0, h, A, B, cy);
@@ -272,7 +272,7 @@ struct NetV3 {
         }
         {
             Act x[KT0][NT];
-            inputs(w0, w1, x);
+            inputs(w0, w1, x, std::integral_constant<int, 1>{});
             dense_act_chain<Mode, KT0, HT, NT, true, kCarryPre, kCarryTail>(pipe, b_g1, b_g2, h, x, A, cy);
         }
         dense_act_chain<Mode, HT, HT, NT, true, kCarryTail, kCarryTail>(pipe, b_g2, b_op, h, A, B, cy);
@@ -370,6 +370,50 @@ __device__ __forceinline__ void dino_scaled_tiles(const float (&e)[16 * DT], flo
         out[t] = Mode::template to_act<false>(v);
     }
 }
+
+// What a column of the fused V3 renderer keeps of its gathered feature-map channels between NetV3's two fusion passes (the
+// gather -- two rounds of global loads whose latency a lone wave cannot cover -- happens once per sample).
+//   * fp32-class modes (Act = 16 registers per tile): the blended fp32 channels, 16 DT registers; both passes are exact.
+//   * 16-bit modes: the FIRST pass's own operand tiles (the channels rounded to 16 bits, 8 DT registers: half the hold --
+//     with fp32 channels the dino_dim-128 kernels spilled 71-87 VGPRs, the dino_dim-64 ones 17-33).  The second pass
+//     rescales THOSE by the gate: round16(round16(e) * w1) instead of round16(e * w1) -- one more 16-bit rounding of an input
+//     (<= 2^-11 relative in f16, 2^-8 in bf16: the size of the operand rounding that follows it anyway).
+template <class Mode, int DT, bool PACKED = (sizeof(typename Mode::Act) == 32)>
+struct DinoHeld {
+    float e[16 * DT];
+    __device__ __forceinline__ void gather(const float* __restrict__ feat, const DinoTaps& tp, int h) { dino_blend<DT>(feat, tp, h, e); }
+    template <int PASS>
+    __device__ __forceinline__ void tiles(float scale, typename Mode::Act (&out)[DT]) const { dino_scaled_tiles<Mode, DT>(e, scale, out); }
+};
+
+template <class Mode, int DT>
+struct DinoHeld<Mode, DT, true> {
+    typename Mode::Act t[DT];
+    __device__ __forceinline__ void gather(const float* __restrict__ feat, const DinoTaps& tp, int h) {
+        float e[16 * DT];
+        dino_blend<DT>(feat, tp, h, e);
+        dino_scaled_tiles<Mode, DT>(e, 1.0f, t);
+    }
+    template <int PASS>
+    __device__ __forceinline__ void tiles(float scale, typename Mode::Act (&out)[DT]) const {
+#pragma unroll
+        for (int k = 0; k < DT; ++k) {
+            if constexpr (PASS == 0) {
+                out[k] = t[k];                                   // first pass: the gate is 1
+            } else {
+                typedef __attribute__((ext_vector_type(8))) float f32x8;
+                f32x16 v;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const f32x8 w = __builtin_convertvector(t[k].f[s], f32x8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[8 * s + j] = w[j] * scale;
+                }
+                out[k] = Mode::template to_act<false>(v);
+            }
+        }
+    }
+};
 
 template <class Mode, int DT>
 __device__ __forceinline__ void dino_tiles(const float* __restrict__ feat, const DinoTaps& tp, int h, float scale,

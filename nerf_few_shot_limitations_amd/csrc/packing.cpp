@@ -316,7 +316,10 @@ PackedStream pack_stream(const NetPlan& plan, const std::vector<HostLinear>& lin
     out.n_chunks = (uint32_t)(src.size() / per_frag / kChunkFrags);
     out.bytes.assign(src.size() / per_frag * kFragBytes, 0);
     for (size_t i = 0; i < src.size(); ++i) {
-        const float v = src[i] >= 0 ? flat[src[i]] : 0.0f;
+        float v = src[i] >= 0 ? flat[src[i]] : 0.0f;
+        // f16-typed streams saturate at the largest finite f16: an out-of-range weight would otherwise become inf (and the split
+        // mode's low part -inf, their products NaN).  No trained NeRF comes near it; a diverged checkpoint renders saturated, not NaN.
+        if (!f32 && mode != NRF_MMA_BF16) v = std::fmin(std::fmax(v, -65504.0f), 65504.0f);
         if (f32) {
             std::memcpy(out.bytes.data() + i * 4, &v, 4);
         } else if (x3) {

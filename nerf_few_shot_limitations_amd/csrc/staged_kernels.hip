@@ -265,6 +265,69 @@ __device__ __forceinline__ int count_lt(const float* a, int n, int top, float x)
 }
 __host__ __device__ inline int top_pow2(int n) { int t = 1; while (t * 2 <= n) t *= 2; return t; }
 
+// ---- the two reductions of ray_utils.py:107-109 in the order PyTorch's CPU kernels use (what "the reference's CPU renderer" computes) ----
+// `weights.sum(-1)` (:107) is ATen's cascade_sum (aten/src/ATen/native/cpu/SumKernel.cpp): the contiguous row is read as vectors of
+// 8 floats (also on AVX-512 hosts: checked bit for bit against torch 2.10 for S = 16 ... 4096 in the build container), four
+// interleaved vector accumulators (ILP), each a cascade of 16-vector blocks over up to four levels; then the scalar tail, then the
+// eight lanes left to right.  Lane l < 8 of the wave plays vector lane l; the result is broadcast.
+__device__ __forceinline__ int ceil_log2_i(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+__device__ float torch_cpu_row_sum(const float* x, int S, int lane) {
+    constexpr int V = 8, ILP = 4, LEVELS = 4;
+    const int vec_size = S / V, size_ilp = vec_size / ILP;
+    const int l = lane & (V - 1);
+    float acc[LEVELS][ILP];
+#pragma unroll
+    for (int j = 0; j < LEVELS; ++j)
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) acc[j][k] = 0.0f;
+    const int quarter = ceil_log2_i(size_ilp) / LEVELS;
+    const int level_power = quarter > 4 ? quarter : 4;
+    const int level_step = 1 << level_power, level_mask = level_step - 1;
+    int i = 0;
+    while (i + level_step <= size_ilp) {
+        for (int j = 0; j < level_step; ++j, ++i)
+#pragma unroll
+            for (int k = 0; k < ILP; ++k) acc[0][k] = __fadd_rn(acc[0][k], x[(i * ILP + k) * V + l]);
+        bool go = true;
+#pragma unroll
+        for (int j = 1; j < LEVELS; ++j) {
+            if (go) {
+#pragma unroll
+                for (int k = 0; k < ILP; ++k) { acc[j][k] = __fadd_rn(acc[j][k], acc[j - 1][k]); acc[j - 1][k] = 0.0f; }
+                if ((i & (level_mask << (j * level_power))) != 0) go = false;
+            }
+        }
+    }
+    for (; i < size_ilp; ++i)
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) acc[0][k] = __fadd_rn(acc[0][k], x[(i * ILP + k) * V + l]);
+#pragma unroll
+    for (int j = 1; j < LEVELS; ++j)
+#pragma unroll
+        for (int k = 0; k < ILP; ++k) acc[0][k] = __fadd_rn(acc[0][k], acc[j][k]);
+    for (int v = size_ilp * ILP; v < vec_size; ++v) acc[0][0] = __fadd_rn(acc[0][0], x[v * V + l]);
+#pragma unroll
+    for (int k = 1; k < ILP; ++k) acc[0][0] = __fadd_rn(acc[0][0], acc[0][k]);
+    float fin = 0.0f;
+    for (int k = vec_size * V; k < S; ++k) fin = __fadd_rn(fin, x[k]);
+#pragma unroll
+    for (int k = 0; k < V; ++k) fin = __fadd_rn(fin, __shfl(acc[0][0], k, 64));
+    return fin;
+}
+
+// `torch.cumsum` (:108) on the CPU accumulates in DOUBLE and rounds every prefix to float (ReduceOpsKernel.cpp: acc_type<float,
+// false>; verified against torch 2.10).  For compositing weights (pdf >= 2^-18, sums < 2) every partial sum is a multiple of 2^-41
+// below 2, i.e. exact in a double: the wave-parallel scan below then equals the sequential one bit for bit.
+__device__ __forceinline__ double wave_incl_sum_f64(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double u = __shfl_up(v, d, 64);
+        if (lane >= d) v = v + u;
+    }
+    return v;
+}
+
 __global__ void sample_pdf_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t n_rays, int S, int Ni,
                                   const float* __restrict__ u_in, float* __restrict__ samples, float* __restrict__ z_union) {
     extern __shared__ float lds_rows[];
@@ -282,23 +345,22 @@ __global__ void sample_pdf_kernel(const float* __restrict__ z, const float* __re
     for (int64_t r = wave0; r < n_rays; r += n_waves) {
         const float* zr = z + r * S;
         const float* wr = w + r * S;
-        // sum(weights + 1e-5) (:104,:107); the shifted weights are parked in the cdf row
-        float part = 0.0f;
+        // weights + 1e-5 (:104), parked in the cdf row; their sum (:107) in PyTorch's CPU order
         for (int s = lane; s < S; s += 64) {
-            const float v = __fadd_rn(wr[s], 1e-5f);
-            cdf[s + 1] = v;
+            cdf[s + 1] = __fadd_rn(wr[s], 1e-5f);
             zl[s] = zr[s];
-            part = __fadd_rn(part, v);
         }
-        const float total = wave_sum(part);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        // cdf = [0, cumsum(pdf)] (:108-109): prefix sums of 64-sample segments, carried from segment to segment
-        float carry = 0.0f;
+        const float total = torch_cpu_row_sum(cdf + 1, S, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        // cdf = [0, cumsum(pdf)] (:108-109): double-precision prefix sums of 64-sample segments, carried from segment to segment,
+        // every knot rounded to float -- torch.cumsum's CPU arithmetic, so that the `denom < 1e-5` guard (:131) decides alike
+        double carry = 0.0;
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int s = s0 + lane;
             const float pdf = s < S ? cdf[s + 1] / total : 0.0f;
-            const float incl = __fadd_rn(carry, wave_incl_sum(pdf, lane));
-            if (s < S) cdf[s + 1] = incl;
+            const double incl = carry + wave_incl_sum_f64((double)pdf, lane);
+            if (s < S) cdf[s + 1] = (float)incl;
             carry = __shfl(incl, 63, 64);
         }
         if (lane == 0) cdf[0] = 0.0f;

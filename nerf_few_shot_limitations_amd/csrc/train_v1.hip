@@ -13,6 +13,8 @@ namespace nrf {
 // fragments carry the low parts: packing.cpp:pack_stream)
 __device__ __forceinline__ uint32_t convert_pair(float a, float b, int mode, int64_t pair) {
     if (mode == NRF_MMA_BF16) return (uint32_t)pack_pair<bf16x2, false>(a, b);
+    a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);      // f16-typed streams saturate (packing.cpp:pack_stream does the same on the host)
+    b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
     if (mode == NRF_MMA_F16X3 && ((pair >> 8) & 1)) {
         const f32x2 ab = {a, b};
         const f32x2 hf = __builtin_convertvector(__builtin_convertvector(ab, f16x2), f32x2);

@@ -52,8 +52,20 @@ def _opts(near, far, n_samples, perturb, t_rand, seed, lindisp, ert_eps, white_b
 def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb=False, t_rand=None, seed=None, lindisp=False,
                 ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, return_weights=True, return_z=False,
                 z_in=None):
-    """Render explicit rays (R,3)/(H,W,3) -> {'rgb' (R,3), 'depth' (R,), 'weights' (R,S)[, 'z_vals' (R,S)]}."""
+    """Render explicit rays (R,3)/(H,W,3) -> {'rgb' (R,3), 'depth' (R,), 'weights' (R,S)[, 'z_vals' (R,S)]}.
+    Under torch.no_grad() (evaluate, train.py:294) this is ONE fused kernel launch.  With grad enabled and parameters that
+    require it (train_step, train.py:280-287) the same call returns tensors with a grad_fn: the staged training kernels behind
+    one autograd node (training.render_rays_train), so `loss.backward(); optimizer.step()` work on the drop-in unchanged."""
     L.require_gpu()
+    if model._wants_grad():
+        from .training import render_rays_train
+        out = render_rays_train(model, rays_o, rays_d, near, far, N_samples, perturb=perturb, t_rand=t_rand, seed=seed, lindisp=lindisp,
+                                white_bkgd=white_bkgd, dino=dino, z_in=z_in)
+        if not return_weights:
+            out.pop("weights")
+        if not return_z:
+            out.pop("z_vals")
+        return out
     o = L.dev_f32(rays_o).reshape(-1, 3)
     d = L.dev_f32(rays_d, o.device).reshape(-1, 3)
     R, S = o.shape[0], int(N_samples)
@@ -148,8 +160,8 @@ class NeRFRenderer:
         idx = view_idx if self.nerf_model.training else 0          # train.py:203-208
         return dict(features=self.dino_features_precomputed[idx], pose=self.poses[idx], focal=self.focal, H=self.H, W=self.W)
 
-    @torch.no_grad()
     def render_rays(self, rays_o, rays_d, view_idx=0, N_samples=64):
+        """train.py:188: differentiable under grad mode (train_step), the fused kernel under torch.no_grad() (evaluate)."""
         return render_rays(self.nerf_model, rays_o, rays_d, self.near, self.far, N_samples,
                            perturb=self.nerf_model.training, white_bkgd=self.white_bkgd, mma_mode=self.mma_mode,
                            ert_eps=self.ert_eps, dino=self._dino(view_idx))

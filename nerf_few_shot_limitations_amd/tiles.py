@@ -96,8 +96,22 @@ class TileJob:
             self.buf = torch.zeros((self.V, self.per_rank * self.tile_rays, 4), dtype=torch.float32, device=self.device)
 
     @property
+    def views_per_launch(self):
+        """8 views per launch when the tiles deal evenly over the ranks (every rank's buffer is all real tiles), else one."""
+        return 8 if self.n_real == self.per_rank else 1
+
+    @property
+    def launches_per_step(self):
+        return 0 if self.n_real == 0 else -(-self.V // self.views_per_launch)
+
+    @property
+    def rays_per_step(self):
+        """Rays this rank marches per `launch()`: all views x its real tiles."""
+        return self.V * self.n_real * self.tile_rays
+
+    @property
     def rays_per_launch(self):
-        return min(8, self.V) * self.n_real * self.tile_rays
+        return min(self.views_per_launch, self.V) * self.n_real * self.tile_rays
 
     def launch(self):
         """Enqueue the render kernel(s): they write this rank's tiles straight into the gather buffer `self.buf`
@@ -108,15 +122,20 @@ class TileJob:
         if n == 0:
             return
         even = self.n_real == self.per_rank
-        step = 8 if even else 1
+        step = self.views_per_launch
+        seed0 = int(self.opts.rng_seed)
         with torch.cuda.device(self.device):
             for v0 in range(0, self.V, step):
                 nv = min(step, self.V - v0)
                 sub = (C.c_float * (12 * nv)).from_buffer(self.poses, 4 * 12 * v0)
                 out = self.buf[v0:v0 + nv] if even else self.buf[v0, :n]
+                # the kernel keys a view's jitter by seed + (camera index inside the launch) * 0x51ED27: offset the seed by the
+                # launch's first view so that the pattern is a function of the GLOBAL view index, however the views are batched
+                self.opts.rng_seed = (seed0 + v0 * 0x51ED27) & 0xFFFFFFFFFFFFFFFF
                 L.check(L.lib().nrf_render_cameras_tiles(h, self.H, self.W, self.focal, C.cast(sub, C.c_void_p), nv, self.tile_rays,
                                                          self.rank, self.world, self.n_real, C.byref(self.opts),
                                                          L.ptr(out), None, None, None, L.stream_ptr()))
+        self.opts.rng_seed = seed0
 
     def pack(self):
         """The gather buffer (kept for callers of the round-1 interface: the kernel has already written it)."""

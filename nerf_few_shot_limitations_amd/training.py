@@ -269,6 +269,132 @@ def composite(rgb_sigma, z, d, white_bkgd=False):
 
 
 # ---------------------------------------------------------------------------------------------
+# render_rays with grad enabled: the trainer-shaped entry point (train.py:188-242 inside train_step, :280-287)
+# ---------------------------------------------------------------------------------------------
+class _RenderFn(torch.autograd.Function):
+    """Per-sample network inputs + depths + rays -> (rgb (R,3), depth (R,), weights (R,S)), differentiable with respect to the
+    parameters: ONE autograd node over the kernels FusedStep runs (saving forward -> composite | composite backward -> dZ
+    chain + weight gradients), so `loss.backward()` of the reference's unmodified train_step body lands in the parameters'
+    .grad (views of the module's flat gradient vector)."""
+
+    @staticmethod
+    def forward(ctx, module, x, dirs, dino, z, d, white, *params):
+        dev = z.device
+        R, S = z.shape
+        n = R * S
+        h, mode = _train_handle(module, dev)
+        v1 = module.net == L.NRF_NET_V1
+        lib = L.lib()
+        with torch.cuda.device(dev):
+            nbytes = lib.nrf_train_context_bytes(h, mode, n)
+            if nbytes < 0:
+                raise L.NrfError(-2, lib.nrf_last_error().decode("utf-8", "replace"))
+            buf = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
+            o4 = torch.empty((n, 4), dtype=torch.float32, device=dev)          # V1: [r,g,b,sigma] rows; V2/V3: rgb (n,3) | density (n,1)
+            out_rgb = torch.empty((R, 3), dtype=torch.float32, device=dev)
+            out_depth = torch.empty((R,), dtype=torch.float32, device=dev)
+            out_w = torch.empty((R, S), dtype=torch.float32, device=dev)
+            st, cb = L.stream_ptr(), C.c_void_p(buf.data_ptr())
+            if v1:
+                L.check(lib.nrf_mlp_forward_train_v1(h, mode, L.ptr(x), n, L.ptr(o4), cb, nbytes, st))
+                L.check(lib.nrf_composite(L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, white,
+                                          L.ptr(out_rgb), L.ptr(out_depth), L.ptr(out_w), st))
+            else:
+                rgb, den = o4.view(-1)[:3 * n].view(n, 3), o4.view(-1)[3 * n:].view(n, 1)
+                L.check(lib.nrf_mlp_forward_train(h, mode, L.ptr(x), L.ptr(dirs), L.ptr(dino), n, L.ptr(rgb), L.ptr(den), cb, nbytes, st))
+                L.check(lib.nrf_composite(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, white, L.ptr(out_rgb), L.ptr(out_depth), L.ptr(out_w), st))
+        ctx.module, ctx.buf, ctx.nbytes, ctx.mode, ctx.white, ctx.v1 = module, buf, nbytes, mode, white, v1
+        ctx.versions = module._versions()
+        ctx.save_for_backward(o4, z, d)
+        ctx.set_materialize_grads(False)
+        return out_rgb, out_depth, out_w
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_w):
+        module = ctx.module
+        if module._versions() != ctx.versions:
+            raise RuntimeError("NeRFMLP parameters were modified between render_rays and backward: the saved activations "
+                               "no longer match the packed weights")
+        o4, z, d = ctx.saved_tensors
+        R, S = z.shape
+        n = R * S
+        dev = z.device
+        lib = L.lib()
+
+        def prep(g):
+            return None if g is None else g.to(torch.float32).contiguous()
+        g_rgb, g_depth, g_w = prep(g_rgb), prep(g_depth), prep(g_w)
+        n_in = 7
+        fp = module.flat_params()
+        if g_rgb is None and g_depth is None and g_w is None:
+            return (None,) * (n_in + len(fp.offsets))
+        direct = _grad_target(module)
+        grad = direct if direct is not None else torch.zeros_like(fp.flat)
+        with torch.cuda.device(dev):
+            d4 = torch.empty_like(o4)
+            st, cb = L.stream_ptr(), C.c_void_p(ctx.buf.data_ptr())
+            if ctx.v1:
+                L.check(lib.nrf_composite_backward(L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, ctx.white,
+                                                   L.ptr(g_rgb), L.ptr(g_depth), L.ptr(g_w), L.ptr(d4), 4, C.c_void_p(d4.data_ptr() + 12), 4, st))
+                L.check(lib.nrf_mlp_backward_v1(module._handle, ctx.mode, L.ptr(o4), L.ptr(d4), n, cb, ctx.nbytes, L.ptr(grad), st))
+            else:
+                rgb, den = o4.view(-1)[:3 * n].view(n, 3), o4.view(-1)[3 * n:].view(n, 1)
+                d_rgb, d_den = d4.view(-1)[:3 * n].view(n, 3), d4.view(-1)[3 * n:].view(n, 1)
+                L.check(lib.nrf_composite_backward(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, ctx.white,
+                                                   L.ptr(g_rgb), L.ptr(g_depth), L.ptr(g_w), L.ptr(d_rgb), 3, L.ptr(d_den), 1, st))
+                L.check(lib.nrf_mlp_backward(module._handle, ctx.mode, L.ptr(rgb), L.ptr(den), L.ptr(d_rgb), L.ptr(d_den), n, cb, ctx.nbytes,
+                                             L.ptr(grad), st))
+        ctx.buf = None
+        if direct is not None:
+            return (None,) * (n_in + len(fp.offsets))
+        return (None,) * n_in + tuple(fp.views(grad))
+
+
+_encoders = {}
+
+
+def render_rays_train(module, rays_o, rays_d, near, far, n_samples, perturb=True, t_rand=None, seed=None, lindisp=False,
+                      white_bkgd=False, dino=None, z_in=None):
+    """renderer.render_rays when grad is enabled: the reference's own sequence (train.py:188-242) -- stratified samples,
+    [project + fetch DINO features,] NeRFMLP, VolumeRenderer -- returning {'rgb','depth','weights','z_vals'} that carry a grad_fn.
+    Gradients reach the parameters only (rays, depths and features are data: a tensor that requires grad is refused).
+    The arithmetic mode is the module's own training mode (_lib.TRAIN_MODE); early ray termination does not apply."""
+    from .ray_sampler import sample_points_along_rays
+    o = L.dev_f32(L.refuse_grad(rays_o, "render_rays(rays_o)")).reshape(-1, 3)
+    d = L.dev_f32(L.refuse_grad(rays_d, "render_rays(rays_d)"), o.device).reshape(-1, 3)
+    R, S = o.shape[0], int(n_samples)
+    if z_in is not None:
+        z = L.dev_f32(z_in, o.device).reshape(R, S)
+        pts = o[:, None, :] + d[:, None, :] * z[:, :, None]
+    else:
+        pts, z = sample_points_along_rays(o, d, near, far, S, perturb=perturb, lindisp=lindisp, t_rand=t_rand, seed=seed)
+    pts = pts.reshape(-1, 3)
+    dirs = feats = None
+    if module.net == L.NRF_NET_V1:
+        from .positional_encoding import PositionalEncoding
+        enc = _encoders.get(module.pos_freq)
+        if enc is None:
+            enc = _encoders[module.pos_freq] = PositionalEncoding(module.pos_freq)
+        x = enc(pts)                                                     # train_minimal.py:101
+    else:
+        x = pts
+        dirs = d[:, None, :].expand(R, S, 3).reshape(-1, 3).contiguous()          # train.py:225: raw ray directions per sample
+        if module.net == L.NRF_NET_V3:
+            if dino is None:
+                raise ValueError("a use_dino model needs dino=dict(features=, pose=, focal=, H=, W=)")
+            if getattr(dino.get("features"), "requires_grad", False):
+                raise NotImplementedError("no gradient with respect to the DINO feature map is produced; detach it")
+            from .renderer import make_dino
+            dn, keep = make_dino(**dino)
+            feats = torch.empty((R * S, module.dino_dim), dtype=torch.float32, device=o.device)
+            with torch.cuda.device(o.device):
+                L.check(L.lib().nrf_project_fetch(C.byref(dn), L.ptr(pts), R * S, L.ptr(feats), None, L.stream_ptr()))   # train.py:203-217
+            del keep
+    rgb, depth, w = _RenderFn.apply(module, x, dirs, feats, z, d, int(bool(white_bkgd)), *module.flat_params().params())
+    return {"rgb": rgb, "depth": depth, "weights": w, "z_vals": z}
+
+
+# ---------------------------------------------------------------------------------------------
 # optimizer
 # ---------------------------------------------------------------------------------------------
 class Adam:

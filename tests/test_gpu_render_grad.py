@@ -1,0 +1,135 @@
+"""render_rays with grad enabled (SURVEY.md section 8b row `render_rays`): the body of the reference's
+train_step (src/training/train.py:280-287)
+
+    predictions = self.render_rays(ray_batch_o, ray_batch_d, view_idx, N_samples)
+    loss = sum(criterion(predictions, {'rgb': target}).values()); optimizer.zero_grad(); loss.backward(); optimizer.step()
+
+runs unchanged on the drop-in surface (NeRFRenderer.render_rays) and reproduces the same loop on the CPU oracle.
+The stratified jitter is the one input the oracle cannot draw itself (in-kernel counter RNG): the depths the GPU used are
+re-derived with the staged sampling kernel under the same seed (itself checked against the reference in test_gpu_parity.py)
+and handed to the CPU loop.  Tolerance: losses within 2e-4 relative (fp32 mode: summation order only).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def N():
+    import nerf_few_shot_limitations_amd as N
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from nerf_few_shot_limitations_amd import _lib
+    _lib.lib()
+    return N
+
+
+def build(N, net, mode="f32"):
+    if net == "v1":
+        m = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=mode)
+        p = O.make_weights("v1", 0, "solid")
+        m.load_state_dict(p)
+    elif net == "v2":
+        m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=False, mma_mode=mode)
+        p = O.make_weights("v2", 1, "solid")
+        m.load_state_dict(p, strict=False)
+    else:
+        m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=True, dino_dim=64, mma_mode=mode)
+        p = O.make_weights("v3", 2, "solid")
+        m.load_state_dict(p, strict=False)
+    return m.cuda().train(), p
+
+
+def mse_criterion(predictions, targets):           # train.py:36-44 (the NeRFLoss train.py defines): {'rgb_loss': w * mse}
+    return {"rgb_loss": 1.0 * torch.nn.functional.mse_loss(predictions["rgb"], targets["rgb"])}
+
+
+@pytest.mark.parametrize("net", ["v2", "v3", "v1"])
+def test_train_step_body_on_the_drop_in_render_rays(N, net):
+    from nerf_few_shot_limitations_amd import _lib
+    H = W = 16
+    R, S, steps = 96, 24, 3
+    c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
+    focal = O.focal_for(W)
+    ro, rd = O.get_rays(H, W, focal, c2w)
+    ro, rd = ro.reshape(-1, 3)[40:40 + R].contiguous(), rd.reshape(-1, 3)[40:40 + R].contiguous()
+    target = torch.from_numpy(O.uniform01(8, R * 3).reshape(R, 3)).float()
+    fmaps = torch.from_numpy(O.uniform01(7, 2 * 9 * 9 * 64).reshape(2, 9, 9, 64) * 2 - 1).float()
+    poses = torch.stack([c2w, c2w.clone()])
+    poses[1, 0, 3] += 0.3
+    view_idx = 1
+
+    model, p = build(N, net)
+    renderer = N.NeRFRenderer(model, 2.0, 6.0, dino_features=[fmaps[0:1].cuda(), fmaps[1:2].cuda()] if net == "v3" else None,
+                              poses=poses, focal=focal, H=H, W=W)
+    optimizer = torch.optim.Adam(model.parameters(), lr=5e-4, weight_decay=1e-6)      # train.py:113-118, baseline.yaml:39-40
+    ro_d, rd_d, tgt_d = ro.cuda(), rd.cuda(), target.cuda()
+    gpu_losses, zs = [], []
+    for k in range(steps):
+        torch.manual_seed(100 + k)
+        seed = _lib.fresh_seed()                   # the seed the call below will draw (same generator state)
+        torch.manual_seed(100 + k)
+        # ---- train.py:280-287, verbatim in shape ----
+        predictions = renderer.render_rays(ro_d, rd_d, view_idx, S)
+        loss_dict = mse_criterion(predictions, {"rgb": tgt_d})
+        loss = sum(loss_dict.values())
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        # ---------------------------------------------
+        assert predictions["rgb"].grad_fn is not None and predictions["depth"].grad_fn is not None and predictions["weights"].grad_fn is not None
+        assert predictions["rgb"].shape == (R, 3) and predictions["depth"].shape == (R,) and predictions["weights"].shape == (R, S)
+        gpu_losses.append(loss.item())
+        with torch.no_grad():
+            zs.append(N.sample_points_along_rays(ro_d, rd_d, 2.0, 6.0, S, perturb=True, seed=seed)[1].cpu())
+    assert all(q.grad is not None for q in model.parameters())
+
+    # the same loop on the CPU oracle, on the depths the GPU marched
+    pp = {k: torch.nn.Parameter(v.clone()) for k, v in p.items()}
+    opt = torch.optim.Adam(list(pp.values()), lr=5e-4, weight_decay=1e-6)
+    cpu_losses = []
+    for k in range(steps):
+        z = zs[k]
+        assert not torch.equal(z, O.sample_points_along_rays(ro, rd, 2.0, 6.0, S)[1])         # training mode: jittered
+        pts = (ro[:, None, :] + rd[:, None, :] * z[:, :, None]).reshape(-1, 3)
+        dirs = rd[:, None, :].expand(R, S, 3).reshape(-1, 3)
+        opt.zero_grad()
+        if net == "v1":
+            out = O.mlp_v1(pp, O.positional_encoding(pts, 10))
+            rgb, den = out[:, :3], out[:, 3:4]
+        elif net == "v2":
+            rgb, den = O.mlp_v2(pp, pts, dirs)
+        else:
+            xy, _, _ = O.project_points_to_image(pts, poses[view_idx], focal, H, W)          # training: the view's own map (train.py:203-206)
+            rgb, den = O.mlp_v3(pp, pts, dirs, O.sample_features_at_points(fmaps[view_idx:view_idx + 1], xy))
+        pred = O.volume_render(rgb.reshape(R, S, 3), den.reshape(R, S, 1), z, rd)[0]
+        loss = torch.nn.functional.mse_loss(pred, target)
+        loss.backward()
+        opt.step()
+        cpu_losses.append(loss.item())
+    assert np.allclose(cpu_losses, gpu_losses, rtol=2e-4, atol=1e-6), (cpu_losses, gpu_losses)
+
+
+def test_render_rays_is_the_fused_kernel_under_no_grad_and_differentiable_otherwise(N):
+    """One call surface, two routes: no_grad -> one fused launch (no grad_fn); grad mode -> autograd node.  Same numbers
+    (fp32 mode, no jitter in eval mode) to 1e-5."""
+    model, _ = build(N, "v2")
+    c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
+    ro, rd = O.get_rays(12, 12, O.focal_for(12), c2w)
+    ro, rd = ro.reshape(-1, 3).cuda(), rd.reshape(-1, 3).cuda()
+    renderer = N.NeRFRenderer(model.eval(), 2.0, 6.0)
+    with torch.no_grad():
+        fused = renderer.render_rays(ro, rd, 0, 32)
+    assert fused["rgb"].grad_fn is None
+    staged = renderer.render_rays(ro, rd, 0, 32)                 # eval mode, grad enabled: differentiable, perturb off
+    assert staged["rgb"].grad_fn is not None
+    for k in ("rgb", "depth", "weights"):
+        assert (fused[k] - staged[k].detach()).abs().max() < 1e-5, k
+    staged["depth"].sum().backward()                             # a loss on depth alone reaches the parameters too
+    assert all(q.grad is not None for q in model.parameters())
+    # rays that require grad are refused, not silently detached
+    with pytest.raises(NotImplementedError):
+        renderer.render_rays(ro.clone().requires_grad_(True), rd, 0, 32)

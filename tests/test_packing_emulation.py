@@ -225,3 +225,42 @@ def test_config_yaml_near_far_resolution(tmp_path):
     assert m.flops_per_sample() == 1170560
     assert N.render_settings(cfg)["n_samples"] == 64
     assert set(m.state_dict()) >= {"density_mlp.density_layers.0.weight", "density_mlp.feature_head.bias", "color_mlp.color_layers.4.weight"}
+
+
+def test_out_rgbd_rows_must_be_16_byte_aligned(L):
+    """the kernels write an out_rgbd row with one 16-byte store; a float-aligned base is refused with NRF_EINVAL
+    before anything else is looked at (no GPU needed: the check precedes the model check)."""
+    lib = L.lib()
+    o = L.nrf_render_opts()
+    o.near, o.far, o.n_samples, o.out_rgbd = 2.0, 6.0, 8, 1
+    c2w = (C.c_float * 12)(*([0.0] * 12))
+    for bad in (0x1004, 0x1008, 0x100C):
+        assert lib.nrf_render_rays(None, C.c_void_p(0x2000), C.c_void_p(0x3000), 4, C.byref(o), C.c_void_p(bad), None, None, None, None) == -1
+        assert b"16-byte aligned" in lib.nrf_last_error()
+        assert lib.nrf_render_camera(None, 4, 4, 1.0, c2w, 0, 16, C.byref(o), C.c_void_p(bad), None, None, None, None) == -1
+        assert b"16-byte aligned" in lib.nrf_last_error()
+        assert lib.nrf_render_cameras_tiles(None, 4, 4, 1.0, C.cast(c2w, C.c_void_p), 1, 4, 0, 1, 1, C.byref(o), C.c_void_p(bad), None, None, None, None) == -1
+        assert b"16-byte aligned" in lib.nrf_last_error()
+    # aligned: the next check answers (model is NULL)
+    assert lib.nrf_render_rays(None, C.c_void_p(0x2000), C.c_void_p(0x3000), 4, C.byref(o), C.c_void_p(0x1000), None, None, None, None) == -1
+    assert b"model is NULL" in lib.nrf_last_error()
+    o.out_rgbd = 0                                               # separate outputs: no alignment requirement
+    assert lib.nrf_render_rays(None, C.c_void_p(0x2000), C.c_void_p(0x3000), 4, C.byref(o), C.c_void_p(0x1004), None, None, None, None) == -1
+    assert b"model is NULL" in lib.nrf_last_error()
+
+
+@pytest.mark.parametrize("mode", ["f16", "f16x3"])
+def test_f16_typed_streams_saturate_instead_of_overflowing(L, mode):
+    """a weight beyond the f16 range used to pack as inf (split mode: hi = inf, lo = -inf -> NaN products).  The packer
+    saturates at +-65504; in-range weights pack exactly as before."""
+    p = O.make_weights("v1", 0, "fog")
+    ref, _ = _pack(L, "v1", p, mode)
+    q = {k: v.clone() for k, v in p.items()}
+    q["layers.3.weight"][5, 7] = 1.0e6
+    q["layers.3.weight"][6, 8] = -3.0e5
+    got, _ = _pack(L, "v1", q, mode)
+    a = np.frombuffer(got, np.float16)
+    assert np.isfinite(a.astype(np.float32)).all()
+    assert (a == np.float16(65504)).sum() >= 1 and (a == np.float16(-65504)).sum() >= 1
+    changed = np.frombuffer(got, np.uint16) != np.frombuffer(ref, np.uint16)
+    assert 2 <= changed.sum() <= 4                               # only the two edited weights (hi and lo parts in the split mode)

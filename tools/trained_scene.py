@@ -1,0 +1,151 @@
+"""PSNR delta of every arithmetic mode on a TRAINED field (BASELINE.json: "PSNR within 0.01 dB of reference on lego";
+/root/reference/README.md:31, src/training/train.py:294-342 -- lego itself is not available offline).
+
+A Blender-format scene with real 3-D structure is generated (tools/synthetic_scene.py: ground-truth images by analytic ray
+casting), a field is trained on its train split with experiments/baseline.yaml's schedule through the HIP training path
+(V2: train_cli.train_epoch = train.py:244-292; V1: train_minimal.py:97-123's sequence through the same FusedStep), and the SAME
+trained weights are then rendered in every arithmetic mode on the train views (where the fit -- hence the bar -- is tightest)
+and on the held-out test views.  Reported per split and mode, against the scene's ground-truth images:
+    psnr_db, |psnr - psnr(f32)| (the 0.01 dB bar), max |rgb - rgb(f32)|, max |depth - depth(f32)| (the 1e-4 bar).
+f32 (exact fp32 MFMA) stands for the reference's fp32 arithmetic here: it matches the reference's CPU output to <= 4e-5 in
+tests/test_gpu_parity.py.
+
+    python tools/trained_scene.py [--net v2|v1] [--train-mode bf16] [--epochs 200] [--views 8] [--size 128]
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import synthetic_scene  # noqa: E402
+
+MODES = ("f32", "f16x3", "f16", "bf16")
+
+
+def config(size, views, epochs):
+    """experiments/baseline.yaml's training block at `size` (its own is 128) -- plain dict, the keys train_cli reads."""
+    s = int(size)
+    return {"experiment": {"name": "trained_scene"},
+            "data": {"near": 2.0, "far": 6.0, "resolution": s, "num_views": int(views)},
+            "rendering": {"near": 2.0, "far": 6.0, "chunk_size": 2048, "white_bkgd": False},
+            "model": {"use_dino": False},
+            "nerf_model": {"pos_freq": 10, "dir_freq": 4, "hidden_dim": 256, "num_layers": 8},
+            "training": {"epochs": int(epochs), "batch_size": 1024,
+                         "progressive_schedule": {"epochs_0_50": [s // 4, s // 4, 32], "epochs_50_100": [s // 2, s // 2, 48],
+                                                  "epochs_100_plus": [s, s, 64]}},
+            "optimizer": {"lr": 5.0e-4, "weight_decay": 1.0e-6, "lr_milestones": [100, 150], "lr_gamma": 0.5},
+            "loss": {"rgb_weight": 1.0, "depth_weight": 0.0, "reg_weight": 0.0},
+            "output": {"save_dir": "unused", "val_freq": 10 ** 9, "save_freq": 10 ** 9}}
+
+
+def train_field(net, cfg, scene_dir, train_mode, seed=0, epoch_scale=1.0):
+    """Train on the scene's train split; returns (model, info).  The progressive schedule's stage boundaries (epochs 50 / 100,
+    train.py:249-259) scale with `epoch_scale` when fewer than the YAML's 200 epochs are run."""
+    import nerf_few_shot_limitations_amd as N
+    from nerf_few_shot_limitations_amd import train_cli
+    from nerf_few_shot_limitations_amd.training import FusedStep
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    torch.manual_seed(seed)
+    images, poses, (H, W, focal) = N.load_blender_data(scene_dir, "train", img_size=cfg["data"]["resolution"])
+    images = [im.permute(1, 2, 0).float().to(dev) for im in images[: cfg["data"]["num_views"]]]
+    poses = [p.float() for p in poses[: cfg["data"]["num_views"]]]
+    if net == "v2":
+        model = N.model_from_config(cfg, mma_mode=train_mode)
+    else:
+        model = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=train_mode)       # train_minimal.py:28
+    model = model.to(dev).train()
+    o = cfg["optimizer"]
+    step = FusedStep(model, lr=float(o["lr"]), weight_decay=float(o["weight_decay"]), rgb_weight=1.0)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    epochs = int(cfg["training"]["epochs"])
+    pe = N.PositionalEncoding(10).to(dev)
+    t0 = time.perf_counter()
+    first = last = None
+    samples = 0
+    for epoch in range(epochs):
+        sched_epoch = int(epoch / epoch_scale)                   # which stage of the 200-epoch schedule this epoch stands for
+        step.opt.lr = train_cli.lr_at(cfg, sched_epoch)
+        if net == "v2":
+            loss, n = train_cli.train_epoch(step, cfg, sched_epoch, images, poses, H, W, focal, 2.0, 6.0, gen)
+        else:
+            Ht, Wt, S, batch = train_cli.schedule_for(cfg, sched_epoch)
+            tot, nb, n = None, 0, 0
+            for v in range(len(images)):
+                ro, rd, tgt = train_cli.view_rays(images[v], poses[v], H, W, focal, Ht, Wt)
+                order = torch.randperm(ro.shape[0], device=dev, generator=gen)
+                for i in range(0, order.shape[0], batch):
+                    idx = order[i:i + batch]
+                    pts, z = N.sample_points_along_rays(ro[idx], rd[idx], 2.0, 6.0, S, perturb=True, seed=epoch * 1_000_003 + v * 10_007 + i)
+                    ls = step(pe(pts.reshape(-1, 3)), z, rd[idx], tgt[idx])          # train_minimal.py:100-123
+                    tot = ls if tot is None else tot + ls
+                    nb += 1
+                    n += idx.shape[0] * S
+            loss = float(tot) / max(nb, 1)
+        first = loss if first is None else first
+        last = loss
+        samples += n
+    torch.cuda.synchronize()
+    info = {"net": net, "train_mode": train_mode, "epochs": epochs, "train_views": len(images), "resolution": int(H),
+            "train_seconds": round(time.perf_counter() - t0, 2), "ray_samples_trained": samples,
+            "loss_first_epoch": round(first, 6), "loss_last_epoch": round(last, 6)}
+    return model.eval(), info, (H, W, focal)
+
+
+def compare_modes(model, scene_dir, size, views, modes=MODES, n_samples=64):
+    """Render the train and test views of the scene in every mode; scores against the ground-truth images."""
+    import nerf_few_shot_limitations_amd as N
+    out = {}
+    dev = torch.device("cuda", torch.cuda.current_device())
+    for split in ("train", "test"):
+        images, poses, (H, W, focal) = N.load_blender_data(scene_dir, split, img_size=size)
+        if split == "train":
+            images, poses = images[:views], poses[:views]
+        gt = images.permute(0, 2, 3, 1).contiguous().to(dev)
+        res = {}
+        for mode in modes:
+            with torch.no_grad():
+                r = N.evaluate_views(model, poses, H, W, focal, 2.0, 6.0, n_samples, targets=None, mma_mode=mode)
+            res[mode] = (r["images"], r["depth"], N.psnr(r["images"], gt))
+        ref = res["f32"] if "f32" in res else res[modes[0]]
+        rec = {"views": int(gt.shape[0])}
+        for mode in modes:
+            img, dep, ps = res[mode]
+            rec[mode] = {"psnr_db": round(ps, 4), "psnr_delta_vs_f32_db": round(abs(ps - ref[2]), 5),
+                         "max_abs_rgb_vs_f32": float((img - ref[0]).abs().max()), "max_abs_depth_vs_f32": float((dep - ref[1]).abs().max()),
+                         "meets_0.01dB": bool(abs(ps - ref[2]) <= 0.01),
+                         "meets_1e-4": bool(float((img - ref[0]).abs().max()) <= 1e-4 and float((dep - ref[1]).abs().max()) <= 1e-4)}
+        out[split] = rec
+    return out
+
+
+def run(net="v2", train_mode="bf16", epochs=200, views=8, size=128, test_views=4, seed=0, modes=MODES):
+    """Generate the scene, train, compare: the dict bench.py reports as parity.trained_scene and the GPU test asserts on."""
+    with tempfile.TemporaryDirectory() as tmp:
+        scene = os.path.join(tmp, "scene")
+        synthetic_scene.write_scene(scene, size=size, n_train=views, n_test=test_views)
+        cfg = config(size, views, epochs)
+        model, info, _ = train_field(net, cfg, scene, train_mode, seed, epoch_scale=epochs / 200.0)
+        info.update(compare_modes(model, scene, size, views, modes))
+        info["ground_truth"] = "analytic ray casting of tools/synthetic_scene.py (3x3 supersampled), 8-bit PNGs"
+    return info
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--net", default="v2", choices=["v1", "v2"])
+    ap.add_argument("--train-mode", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--epochs", type=int, default=200)
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--size", type=int, default=128)
+    a = ap.parse_args()
+    print(json.dumps(run(a.net, a.train_mode, a.epochs, a.views, a.size)))

@@ -150,7 +150,18 @@ def main(argv=None):
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
-            dist.init_process_group(backend=backend)
+            # rehearsal only: gloo's transport prints its connection chatter on stdout (C level), where exactly ONE JSON line is
+            # expected -- park fd 1 on stderr while the group comes up
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(backend=backend)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
 
     import nerf_few_shot_limitations_amd as N
     from nerf_few_shot_limitations_amd import tiles

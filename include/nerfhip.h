@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 3
+#define NRF_ABI_VERSION 4
 
 /* error codes */
 #define NRF_OK            0
@@ -183,12 +183,14 @@ int nrf_composite(const float* rgb, int rgb_stride, const float* sigma, int sigm
                   const float* z_vals, const float* rays_d, int64_t n_rays, int n_samples, int white_bkgd,
                   float* out_rgb, float* out_depth, float* out_weights, void* stream);
 /* ray_utils.py:86-143 (intent; the reference function raises):
- * z_vals, weights (R,S) -> samples (R,Ni) and sorted union (R,S+Ni); u (R,Ni) or NULL -> linspace(0,1,Ni).
+ * z_vals, weights (R,S) -> samples (R,Ni) and sorted union (R,S+Ni); u: ray r reads u[r * u_ray_stride + j] -- (R,Ni) rows with
+ * u_ray_stride = Ni, or ONE row shared by all rays with u_ray_stride = 0 (the caller's torch.linspace(0,1,Ni): its last ulp
+ * is host dependent and a nearly empty bin amplifies one ulp of u to 2e-4 of depth) -- or NULL -> linspace(0,1,Ni) in-kernel.
  * The two reductions (:107-109) follow PyTorch's CPU kernels -- weights.sum in ATen's cascade order (8-float vectors),
  * torch.cumsum accumulated in double and rounded per knot -- so the `denom < 1e-5` guard (:131) takes the same branch as the
  * reference's fp32 CPU run would. */
 int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance,
-                   const float* u, float* samples, float* z_union, void* stream);
+                   const float* u, int64_t u_ray_stride, float* samples, float* z_union, void* stream);
 /* ray_utils.py:176-210 + dino_feature_model.py:114-148: points (N,3) -> features (N,C); xy (N,2) may be NULL. */
 int nrf_project_fetch(const nrf_dino* dino, const float* points, int64_t n, float* feats, float* xy, void* stream);
 

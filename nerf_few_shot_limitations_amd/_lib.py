@@ -72,7 +72,7 @@ SIGNATURES = {
     "nrf_mlp_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_composite": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "nrf_sample_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_sample_pdf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_debug_pack": (C.c_int, [C.POINTER(nrf_arch), C.POINTER(nrf_linear), C.c_int, C.c_int, C.c_void_p, C.c_int64,
                                  C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]),
     "nrf_project_fetch": (C.c_int, [C.POINTER(nrf_dino), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -114,7 +114,7 @@ def lib() -> C.CDLL:
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(handle, name)          # AttributeError if the symbol is not exported
                 fn.restype, fn.argtypes = res, args
-            if handle.nrf_abi_version() != 3:
+            if handle.nrf_abi_version() != 4:
                 raise RuntimeError("libnerfhip.so ABI version mismatch")
             for which, st in enumerate((nrf_arch, nrf_linear, nrf_dino, nrf_render_opts)):
                 if handle.nrf_abi_sizeof(which) != C.sizeof(st):
@@ -170,6 +170,21 @@ def require_gpu():
 
 
 _ladders = {}
+_u_rows = {}
+
+
+def u_row(n_importance, device):
+    """torch.linspace(0, 1, Ni) exactly as the reference computes it on THIS host (ray_utils.py:115-116), on `device`: the
+    un-perturbed inverse-cdf arguments shared by all rays (nrf_sample_pdf with u_ray_stride = 0)."""
+    key = (int(n_importance), str(device))
+    u = _u_rows.get(key)
+    if u is None:
+        u = torch.linspace(0., 1., int(n_importance)).to(dtype=torch.float32).to(device).contiguous()
+        if len(_u_rows) > 64:
+            _u_rows.clear()
+        _u_rows[key] = u
+    return u
+
 
 
 def z_ladder(near, far, n_samples, lindisp, device):

@@ -612,12 +612,13 @@ int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
     return r == NRF_OK ? NRF_OK : fail(r, "adam launch failed");
 }
 
-int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance, const float* u,
+int nrf_sample_pdf(const float* z_vals, const float* weights, int64_t n_rays, int n_samples, int n_importance, const float* u, int64_t u_ray_stride,
                    float* samples, float* z_union, void* stream) {
     if (n_rays < 0 || n_samples < 2 || n_importance < 1) return fail(NRF_EINVAL, "bad sizes");
     if (n_rays == 0) return NRF_OK;
     if (!z_vals || !weights || (!samples && !z_union)) return fail(NRF_EINVAL, "null pointer");
-    const int r = nrf::launch_sample_pdf(z_vals, weights, n_rays, n_samples, n_importance, u, samples, z_union, (hipStream_t)stream);
+    if (u && u_ray_stride != 0 && u_ray_stride < n_importance) return fail(NRF_EINVAL, "u_ray_stride must be 0 (one shared row) or >= n_importance");
+    const int r = nrf::launch_sample_pdf(z_vals, weights, n_rays, n_samples, n_importance, u, u_ray_stride, samples, z_union, (hipStream_t)stream);
     return r == NRF_OK ? NRF_OK : fail(r, r == NRF_EINVAL ? "n_samples + n_importance too large for one LDS row" : "sample_pdf launch failed");
 }
 

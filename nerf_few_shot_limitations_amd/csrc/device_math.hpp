@@ -38,6 +38,7 @@ __device__ __forceinline__ void camera_ray(const Camera& c, int64_t ray, float o
 
 struct DepthLadder {      // ray_utils.py:58-66
     float near, far, step;   // step = 1/(S-1) of linspace(0,1,S)
+    float inv_near, inv_far; // 1/near, 1/far of the disparity form (:62)
     int   S, lindisp;
     const float* table;      // optional caller-computed ladder z_0..z_{S-1} (device); see ladder_z
 };
@@ -46,7 +47,19 @@ __host__ __device__ __forceinline__ DepthLadder make_ladder(float near, float fa
     DepthLadder L;
     L.near = near; L.far = far; L.S = S; L.lindisp = lindisp;
     L.step = S > 1 ? 1.0f / (float)(S - 1) : 0.0f;
+    L.inv_near = 1.0f / near; L.inv_far = 1.0f / far;
     L.table = table;
+    return L;
+}
+
+// A wave-uniform float computed by the VALU lives in a VGPR; loop-invariant ones get hoisted, stay live across the MLP (whose register
+// budget is full) and are spilled to SCRATCH -- VMEM traffic in front of the LDS-DMA queue.  Read back through v_readfirstlane they
+// live in SGPRs, whose overflow goes to VGPR lanes (v_writelane), not to memory.
+__device__ __forceinline__ float uniform_f(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
+
+__device__ __forceinline__ DepthLadder make_ladder_uniform(float near, float far, int S, int lindisp, const float* table) {
+    DepthLadder L = make_ladder(near, far, S, lindisp, table);
+    L.step = uniform_f(L.step); L.inv_near = uniform_f(L.inv_near); L.inv_far = uniform_f(L.inv_far);
     return L;
 }
 
@@ -66,8 +79,8 @@ __device__ __forceinline__ float ladder_z(const DepthLadder& L, int s) {
     if (L.table) return L.table[s];
     const float t = ladder_t(L, s);
     if (L.lindisp) {
-        const float a = __fmul_rn(1.0f / L.near, __fsub_rn(1.0f, t));
-        const float b = __fmul_rn(1.0f / L.far, t);
+        const float a = __fmul_rn(L.inv_near, __fsub_rn(1.0f, t));
+        const float b = __fmul_rn(L.inv_far, t);
         return 1.0f / __fadd_rn(a, b);
     }
     return __fadd_rn(__fmul_rn(L.near, __fsub_rn(1.0f, t)), __fmul_rn(L.far, t));
@@ -107,11 +120,19 @@ struct Composite {
     float T, r, g, b, depth, acc;
     __device__ __forceinline__ void reset() { T = 1.0f; r = g = b = depth = acc = 0.0f; }
     // one sample: sigma raw (relu applied here, :193), colour c, depth z, dist = (z_next - z)*|d| or 1e10*|d| (:182-185)
+    // The two halves of a step: the sample's opacity depends on nothing the ray has accumulated -- any lane may compute it -- and the
+    // running state consumes it in order.  add() = add_alpha(alpha_of()): the same operations in the same order wherever they run.
     template <bool FAST>
-    __device__ __forceinline__ float add(float sigma, float cr, float cg, float cb, float z, float dist) {
+    __device__ static __forceinline__ float alpha_of(float sigma, float dist) {
         const float x = __fmul_rn(-fmaxf(sigma, 0.0f), dist);
         const float e = FAST ? __expf(x) : expf(x);
-        const float alpha = __fsub_rn(1.0f, e);
+        return __fsub_rn(1.0f, e);
+    }
+    template <bool FAST>
+    __device__ __forceinline__ float add(float sigma, float cr, float cg, float cb, float z, float dist) {
+        return add_alpha(alpha_of<FAST>(sigma, dist), cr, cg, cb, z);
+    }
+    __device__ __forceinline__ float add_alpha(float alpha, float cr, float cg, float cb, float z) {
         const float w = __fmul_rn(alpha, T);
         r = __fadd_rn(r, __fmul_rn(w, cr));
         g = __fadd_rn(g, __fmul_rn(w, cg));

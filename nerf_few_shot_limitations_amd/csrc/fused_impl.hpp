@@ -113,15 +113,23 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 
     int lane = threadIdx.x & 63, c = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    load_bias_table(bias, P.net.bias, P.net.n_bias);
+    const RenderArgs& a = P.a;
+    const int S = a.n_samples;
+    // a caller-computed depth ladder is cached in LDS when it fits: the owner lane's serial composite of its SPW samples reads one
+    // depth per step, and a dependent GLOBAL load there costs ~0.6 us per sample (17 us per pass at SPW = 32: measured)
+    NRF_LDS float* zl = (NRF_LDS float*)(bias + kBiasMaxFloats) + 16;
+    const bool table = a.z_ladder != nullptr;
+    const bool cached = table && S <= kLadderLds;
+    if (cached)
+        for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder[i];
+    load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
 
     Pipe<WAVES, pinned_walk<Mode, NT>()> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
-    const RenderArgs& a = P.a;
-    const int S = a.n_samples;
-    const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, a.z_ladder);
+    const DepthLadder lad = make_ladder_uniform(a.near, a.far, S, a.lindisp, nullptr);
+    auto z_base = [&](int s) -> float { return cached ? zl[s] : (table ? a.z_ladder[s] : ladder_z(lad, s)); };
     // Samples per ray and MLP pass (host: pick_spw_log2).  The wave's COLS sample columns are RPW = COLS/SPW rays x SPW consecutive
     // samples: column q = ray (q mod RPW), sample (pass*SPW + q div RPW).  A ray is still composited front to back by ONE lane
     // (lane L < RPW owns ray L of the wave; its state rows are the ones of thread L), which fetches the other columns' network
@@ -137,7 +145,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
 
     auto z_ray = [&](int64_t ray, int s) -> float {
         if (a.z_in) return a.z_in[ray * S + s];
-        if (!a.perturb) return ladder_z(lad, s);
+        if (!a.perturb) return z_base(s);
         float u;
         if (a.t_rand) {
             u = a.t_rand[ray * S + s];
@@ -146,7 +154,11 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             const int64_t g = global_ray(a, ray, ci);
             u = counter_uniform(a.seed + (uint64_t)ci * 0x51ED27ull, (uint64_t)g, (uint32_t)s);
         }
-        return ladder_z_jitter(lad, s, u);
+        // ladder_z_jitter (device_math.hpp; ray_utils.py:71-79) on the cached ladder
+        const float zc = z_base(s);
+        const float lower = s > 0 ? __fmul_rn(0.5f, __fadd_rn(zc, z_base(s - 1))) : zc;
+        const float upper = s < S - 1 ? __fmul_rn(0.5f, __fadd_rn(z_base(s + 1), zc)) : zc;
+        return __fadd_rn(lower, __fmul_rn(__fsub_rn(upper, lower), u));
     };
 
     for (int64_t tile = blockIdx.x; tile < P.n_tiles; tile += gridDim.x) {
@@ -169,7 +181,9 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             ST(F_OX) = o[0]; ST(F_OY) = o[1]; ST(F_OZ) = o[2];
             ST(F_DX) = d[0]; ST(F_DY) = d[1]; ST(F_DZ) = d[2];
             ST(F_NORM) = ray_norm(d);
-            ST(F_Z) = z_ray(rid, 0);                 // depth of the ray's next sample to composite
+            int s_first = 0;                         // opaque: z_0 (and the z_1 of its jitter interval) as compile-time constants of the ladder
+            asm volatile("" : "+s"(s_first));        // formula were hoisted out of the tile loop into VGPRs and spilled across the network walk
+            ST(F_Z) = z_ray(rid, s_first);           // depth of the ray's next sample to composite
             ST(F_T) = 1.0f; ST(F_R) = 0.0f; ST(F_G) = 0.0f; ST(F_B) = 0.0f; ST(F_DEPTH) = 0.0f; ST(F_ACC) = 0.0f;
         }
 
@@ -253,6 +267,12 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             Net::eval(pipe, bias, h, P.net.n_layers, inputs, dirT, out4);
 
             // ---- composite this pass's SPW samples of the lane's ray, front to back --------------------------------------
+            // (the lane id once more from an opaque copy: what the compositor derives from it -- 64-bit ray ids, clamps, flags -- would
+            // otherwise be computed before the network walk and carried, i.e. spilled, across it)
+            tid_now = threadIdx.x;
+            asm volatile("" : "+v"(tid_now));
+            lane = tid_now & 63; c = lane & 31; h = lane >> 5;
+            st_me = st + tid_now;
             const int64_t rid = column_ray(lane);
             const int64_t raw = tile * tile_rays + wave * RPW + (lane & (RPW - 1));
             const bool own_valid = lane < RPW && raw < a.n_rays;
@@ -260,40 +280,62 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
             comp.T = ST(F_T); comp.r = ST(F_R); comp.g = ST(F_G); comp.b = ST(F_B); comp.depth = ST(F_DEPTH); comp.acc = ST(F_ACC);
             float zo = ST(F_Z);
             const float norm = ST(F_NORM);
-            for (int j = 0; j < SPW; ++j) {
-                const int s = p * SPW + j;
-                if (s >= S) break;
+            if (SPW == 1) {
+                const int s = p;
 #ifdef NRF_ABLATE_BUILD
-                if (P.net.ablate & 16) { comp.r += out4[0][0] + out4[NT - 1][3]; break; }
+                if (P.net.ablate & 16) { comp.r += out4[0][0] + out4[NT - 1][3]; } else
 #endif
-                const bool last = (s + 1 == S);
-                float v[4];
-                if (SPW == 1) {
+                {
+                    const bool last = (s + 1 == S);
+                    float v[4];
                     // NT == 2: lane L owns column L = tile h, column c -- and holds that tile's head rows itself
 #pragma unroll
                     for (int k = 0; k < 4; ++k) v[k] = NT == 2 ? pick_reg(out4[0][k], out4[NT - 1][k], h != 0) : out4[0][k];
-                } else if (j == 0) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = out4[0][k];
-                } else {
-                    // the outputs of sample s of this lane's ray sit in column q = lane + j*RPW: tile q div 32 (the same for every
-                    // owner lane), lane q mod 32 of the same lane half
-                    const int qj = lane + (j << rpw_log2);
-                    const bool upper = NT == 2 && ((j << rpw_log2) & 32);
-                    const int src = ((lane & 32) | (qj & 31)) << 2;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        v[k] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, NT == 2 ? pick_reg(out4[0][k], out4[NT - 1][k], upper) : out4[0][k])));
+                    const float zn = last ? 0.0f : z_ray(rid, s + 1);
+                    const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zo), norm);
+                    const float w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
+                                                                      sigmoid_sel<Mode::FAST_EXP>(v[2]), zo, dist);
+                    if (own_valid) {
+                        if (a.weights) a.weights[rid * S + s] = w;
+                        if (a.z_vals) a.z_vals[rid * S + s] = zo;
+                    }
+                    zo = zn;
                 }
-                const float zn = last ? 0.0f : z_ray(rid, s + 1);
-                const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zo), norm);
-                const float w = comp.template add<Mode::FAST_EXP>(v[3], sigmoid_sel<Mode::FAST_EXP>(v[0]), sigmoid_sel<Mode::FAST_EXP>(v[1]),
-                                                                  sigmoid_sel<Mode::FAST_EXP>(v[2]), zo, dist);
-                if (own_valid) {
-                    if (a.weights) a.weights[rid * S + s] = w;
-                    if (a.z_vals) a.z_vals[rid * S + s] = zo;
+            } else {
+                // SPW > 1.  Column phase, every lane in parallel: lane q holds the head rows of column q (NT == 2: tile q div 32; NT == 1:
+                // both lane halves hold column c) and its state rows mirror that column's ray -- it turns its sample's network outputs
+                // into (alpha, r, g, b, z): the transcendental part of the step (exp, three sigmoids: ~150 dependent VALU instructions in the
+                // precise modes), which needs nothing of what the ray has accumulated.  Owner phase: lane L < RPW consumes its ray's SPW
+                // samples in order, five ds_bpermute + the six-operation state update per sample.  Same operations on the same values in
+                // the same order as the SPW = 1 march -- only the lane that runs the first half differs.  (Serial in the owner lane, the
+                // whole step cost ~1500 cycles per sample: 20 us per pass at SPW = 32, 40 % on top of the MLP: profiles/r03_small_frames.txt.)
+                const int q = NT == 2 ? lane : c;
+                const int sq = p * SPW + (q >> rpw_log2);
+                float ca = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f, cz = 0.0f;
+                if (sq < S) {
+                    const bool last = (sq + 1 == S);
+                    float v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = NT == 2 ? pick_reg(out4[0][k], out4[NT - 1][k], h != 0) : out4[0][k];
+                    cz = z_ray(rid, sq);
+                    const float zn = last ? 0.0f : z_ray(rid, sq + 1);
+                    const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, cz), norm);
+                    ca = Composite::alpha_of<Mode::FAST_EXP>(v[3], dist);
+                    cr = sigmoid_sel<Mode::FAST_EXP>(v[0]); cg = sigmoid_sel<Mode::FAST_EXP>(v[1]); cb = sigmoid_sel<Mode::FAST_EXP>(v[2]);
                 }
-                zo = zn;
+                for (int j = 0; j < SPW; ++j) {
+                    const int s = p * SPW + j;
+                    if (s >= S) break;
+                    const int qj = lane + (j << rpw_log2);                       // the column of sample s of this (owner) lane's ray
+                    const int src = (NT == 2 ? (qj & 63) : ((lane & 32) | (qj & 31))) << 2;
+                    auto from = [&](float x) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src, __builtin_bit_cast(int, x))); };
+                    const float aj = from(ca), rj = from(cr), gj = from(cg), bj = from(cb), zj = from(cz);
+                    const float w = comp.add_alpha(aj, rj, gj, bj, zj);
+                    if (own_valid) {
+                        if (a.weights) a.weights[rid * S + s] = w;
+                        if (a.z_vals) a.z_vals[rid * S + s] = zj;
+                    }
+                }
             }
             ST(F_T) = comp.T; ST(F_R) = comp.r; ST(F_G) = comp.g; ST(F_B) = comp.b; ST(F_DEPTH) = comp.depth; ST(F_ACC) = comp.acc;
             ST(F_Z) = zo;
@@ -374,7 +416,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
-    const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, nullptr);
+    const DepthLadder lad = make_ladder_uniform(a.near, a.far, S, a.lindisp, nullptr);
     auto z_base = [&](int s) -> float { return cached ? zl[s] : (table ? a.z_ladder[s] : ladder_z(lad, s)); };
     auto z_of = [&](int64_t ray, int s) -> float {
         if (a.z_in) return a.z_in[ray * S + s];
@@ -685,19 +727,26 @@ NetArgs net_args(const DeviceNet& net, int mode) {
     return n;
 }
 
-// Samples per ray and pass (log2; render_kernel): the work items of a launch are tiles of WAVES * 32/SPW rays marched in
-// ceil(S/SPW) passes, dealt to the CUs in whole rounds -- pick the SPW in {1,2,4} with the least rounds x passes (the
-// wider composite costs ~1 % per doubling; ties go to the smaller SPW).  NRF_SPW=0|1|2 pins it (A/B runs; any value is exact).
-inline int pick_spw_log2(int64_t n_rays, int S, int waves, int cu) {
-    static const int pinned = [] { const char* e = getenv("NRF_SPW"); return e ? atoi(e) : -1; }();
-    if (pinned >= 0 && pinned <= 2) return pinned;
+// Samples per ray and pass (log2; render_kernel): the work items of a launch are tiles of WAVES * COLS/SPW rays marched in
+// ceil(S/SPW) passes, dealt to the CUs in whole rounds -- pick the SPW = 1, 2, 4 ... COLS (a wave's columns: ONE ray per wave at the
+// far end) with the least rounds x passes.  What a wider split costs is the owner lane's serial composite of its SPW samples
+// per pass (~0.15 % of an MLP pass per sample: measured, profiles/r03_small_frames.txt); ties go to the smaller SPW.  Small frames live
+// off the far end: 100 x 100 x 32 (BASELINE config 1) is 157 tiles x 8 passes at SPW = 4 -- one round, 61 % of the CUs -- and
+// 1250 tiles x 1 pass = 5 rounds at SPW = 32; a 64 x 64 x 48 validation frame drops from 12 pass-times to 3.  Every choice is exact:
+// a ray's sequence of operations does not depend on it.  NRF_SPW=0..6 pins it (A/B runs).
+inline int pick_spw_log2(int64_t n_rays, int S, int waves, int cols_per_wave, int cu) {
+    const char* env = getenv("NRF_SPW");                 // read per launch: tests walk through every split inside one process
+    const int pinned = (env && *env) ? atoi(env) : -1;
+    int max_l = 0;
+    while ((2 << max_l) <= cols_per_wave) ++max_l;
+    if (pinned >= 0) return pinned < max_l ? pinned : max_l;
     int best = 0;
     double best_t = 0.0;
-    for (int l = 0; l <= 2; ++l) {
-        const int64_t tile = (int64_t)waves * (32 >> l);
+    for (int l = 0; l <= max_l; ++l) {
+        const int64_t tile = (int64_t)waves * (cols_per_wave >> l);
         const int64_t tiles = (n_rays + tile - 1) / tile;
         const int64_t rounds = (tiles + cu - 1) / cu;
-        const double t = (double)rounds * (double)((S + (1 << l) - 1) >> l) * (1.0 + 0.01 * l);
+        const double t = (double)rounds * (double)((S + (1 << l) - 1) >> l) * (1.0 + 0.0015 * (double)(1 << l));
         if (l == 0 || t < best_t * (1.0 - 1e-9)) { best_t = t; best = l; }
     }
     return best;
@@ -712,7 +761,7 @@ int run_render_v(const DeviceNet& net, int mode, const RenderArgs& a, hipStream_
     RenderKArgs k;
     k.net = net_args(net, mode);
     k.a = a;
-    k.a.spw_log2 = pick_spw_log2(a.n_rays, a.n_samples, WAVES * NT, net.cu_count);
+    k.a.spw_log2 = pick_spw_log2(a.n_rays, a.n_samples, WAVES, 32 * NT, net.cu_count);
     const int64_t tile = (int64_t)WAVES * ((32 * NT) >> k.a.spw_log2);
     k.n_tiles = (a.n_rays + tile - 1) / tile;
     const int64_t grid = k.n_tiles < net.cu_count ? k.n_tiles : net.cu_count;

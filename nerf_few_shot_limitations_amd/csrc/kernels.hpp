@@ -124,7 +124,7 @@ int launch_sample(const float* rays_o, const float* rays_d, int64_t n_rays, floa
 int launch_encode(const float* x, int64_t n, int dim, int L, int include_input, const float* freq_bands, float* out, hipStream_t s);
 int launch_composite(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
                      int64_t n_rays, int S, int white_bkgd, float* out_rgb, float* out_depth, float* out_w, hipStream_t s);
-int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, float* samples,
+int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, int64_t u_ray_stride, float* samples,
                       float* z_union, hipStream_t s);
 int launch_project_fetch(const DinoDev& d, const float* points, int64_t n, float* feats, float* xy, hipStream_t s);
 int launch_sample_features(const float* features, int Hp, int Wp, int C, const float* points_2d, int64_t n, float* feats, hipStream_t s);

@@ -316,11 +316,15 @@ __device__ __forceinline__ DinoTaps dino_taps(const DinoT& d, const float p[3]) 
 #pragma unroll
     for (int i = 0; i < 3; ++i)
         pc[i] = d.inv_pose[4 * i + 0] * p[0] + d.inv_pose[4 * i + 1] * p[1] + d.inv_pose[4 * i + 2] * p[2] + d.inv_pose[4 * i + 3];
+    // the camera's wave-uniform constants go through SGPRs (device_math.hpp:uniform_f): as hoisted VGPR values they were spilled
+    const float Wf = uniform_f((float)d.W), Hf = uniform_f((float)d.H), Wpf = uniform_f((float)d.Wp), Hpf = uniform_f((float)d.Hp);
+    const float halfW = uniform_f((float)d.W / 2.0f), halfH = uniform_f((float)d.H / 2.0f);
+    const float Wp1 = uniform_f((float)(d.Wp - 1)), Hp1 = uniform_f((float)(d.Hp - 1));
     const float zi = pc[2] + 1e-8f;
-    const float xn = (pc[0] / zi * d.focal + (float)d.W / 2.0f) / (float)d.W * 2.0f - 1.0f;
-    const float yn = (pc[1] / zi * d.focal + (float)d.H / 2.0f) / (float)d.H * 2.0f - 1.0f;
-    const float gx = ((xn + 1.0f) * (float)d.Wp - 1.0f) * 0.5f;
-    const float gy = ((yn + 1.0f) * (float)d.Hp - 1.0f) * 0.5f;
+    const float xn = (pc[0] / zi * d.focal + halfW) / Wf * 2.0f - 1.0f;
+    const float yn = (pc[1] / zi * d.focal + halfH) / Hf * 2.0f - 1.0f;
+    const float gx = ((xn + 1.0f) * Wpf - 1.0f) * 0.5f;
+    const float gy = ((yn + 1.0f) * Hpf - 1.0f) * 0.5f;
     const float x0 = floorf(gx), y0 = floorf(gy);
     DinoTaps t;
 #pragma unroll
@@ -330,7 +334,7 @@ __device__ __forceinline__ DinoTaps dino_taps(const DinoT& d, const float p[3]) 
             const float xi = x0 + dx, yi = y0 + dy;
             const float wx = dx ? gx - x0 : x0 + 1.0f - gx;
             const float wy = dy ? gy - y0 : y0 + 1.0f - gy;
-            const bool ok = xi >= 0.0f && xi <= (float)(d.Wp - 1) && yi >= 0.0f && yi <= (float)(d.Hp - 1);
+            const bool ok = xi >= 0.0f && xi <= Wp1 && yi >= 0.0f && yi <= Hp1;
             t.off[2 * dy + dx] = ok ? ((int)yi * d.Wp + (int)xi) * d.C : -1;
             t.w[2 * dy + dx] = ok ? wx * wy : 0.0f;
         }

@@ -329,7 +329,7 @@ __device__ __forceinline__ double wave_incl_sum_f64(double v, int lane) {
 }
 
 __global__ void sample_pdf_kernel(const float* __restrict__ z, const float* __restrict__ w, int64_t n_rays, int S, int Ni,
-                                  const float* __restrict__ u_in, float* __restrict__ samples, float* __restrict__ z_union) {
+                                  const float* __restrict__ u_in, int64_t u_ray_stride, float* __restrict__ samples, float* __restrict__ z_union) {
     extern __shared__ float lds_rows[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row_len = 3 * S + 3 * Ni + 1;
@@ -368,7 +368,7 @@ __global__ void sample_pdf_kernel(const float* __restrict__ z, const float* __re
         // inverse cdf (:112-133)
         for (int j = lane; j < Ni; j += 64) {
             float u;
-            if (u_in) u = u_in[r * Ni + j];
+            if (u_in) u = u_in[r * u_ray_stride + j];
             else u = Ni == 1 ? 0.0f : ((j < Ni / 2) ? __fmul_rn(ustep, (float)j) : __fsub_rn(1.0f, __fmul_rn(ustep, (float)(Ni - 1 - j))));
             const int idx = count_le(cdf, S + 1, topS1, u);          // searchsorted(cdf, u, right=True)  (:120)
             const int below = idx - 1 > 0 ? idx - 1 : 0;
@@ -534,8 +534,8 @@ int launch_mse_grad(const float* pred, const float* target, int64_t n, float wei
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 
-int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, float* samples, float* z_union,
-                      hipStream_t s) {
+int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int Ni, const float* u, int64_t u_ray_stride, float* samples,
+                      float* z_union, hipStream_t s) {
     if (n_rays <= 0) return NRF_OK;
     const int row_bytes = (3 * S + 3 * Ni + 1) * 4;          // one wave's LDS rows (cdf, depths, samples, sorted samples, union)
     int waves = 4;
@@ -543,8 +543,8 @@ int launch_sample_pdf(const float* z, const float* w, int64_t n_rays, int S, int
     if (waves * row_bytes > 60 * 1024) return NRF_EINVAL;
     int64_t blocks = (n_rays + waves - 1) / waves;
     if (blocks > 256 * 16) blocks = 256 * 16;                // grid-stride over the rays beyond that
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)blocks), dim3(waves * 64), (size_t)waves * row_bytes, s, z, w, n_rays, S, Ni, u, samples,
-                       z_union);
+    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)blocks), dim3(waves * 64), (size_t)waves * row_bytes, s, z, w, n_rays, S, Ni, u, u_ray_stride,
+                       samples, z_union);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 

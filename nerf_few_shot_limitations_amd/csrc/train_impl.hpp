@@ -308,11 +308,16 @@ struct GradKArgs {
 // matrix core (train_core.hpp) -- each tile exactly once per workgroup -- and parks the transposed operand tiles in
 // LDS, where all waves read the 2 + 4 tiles their outputs need; the saved tiles of the next stage are already in
 // flight (registers) while the current one is multiplied.  Two LDS buffers, one barrier per stage.
-template <class Mode, int ST>
+// PF = stages of saved tiles in flight per wave (registers): the kernel is a stream of 1-KiB tile loads whose only latency cover is
+// what is already in flight -- at PF = 1 (rounds 1-2) a workgroup keeps 2 ST KiB per wave on the wire, 8 MB chip-wide, about half of
+// what 8 TB/s x ~2 us of loaded HBM latency asks for, and the kernel sat at 3.8 TB/s.  PF = 2 doubles it in the 16-bit modes
+// (2 x ST x 16 more registers; the fp32 mode's tiles are twice as large and stay at PF = 1).
+template <class Mode, int ST, int PF = 1>
 __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mode::Act Act;
     typedef ActIO<Mode> IO;
+    static_assert(PF == 1 || PF == 2, "one or two stages of saved tiles in flight");
     constexpr int RT = 2, CT = 4;
     constexpr int TB = tile_bytes<Mode>();
     constexpr int kStageBytes = ST * 16 * TB;
@@ -339,33 +344,33 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
     const char* xb = P.ctx + J.x_off + lane * 16;
     const char* zb = P.ctx + J.dz_off + lane * 16;
     const Act zero = Mode::template to_act<false>(f32x16{});
-    Act rz[ST], rx[ST];
-    auto fetch = [&](int64_t st0) {
+    Act rz[PF][ST], rx[PF][ST];
+    auto fetch = [&](auto b_, int64_t st0) {
+        constexpr int b = decltype(b_)::value;
 #pragma unroll
         for (int q = 0; q < ST; ++q) {
             const bool in = st0 + q < t1;
-            rz[q] = (in && has_z) ? IO::template load<Act>(zb + ((st0 + q) * J.dz_stride + wave) * (int64_t)TB) : zero;
-            rx[q] = (in && has_x) ? IO::template load<Act>(xb + ((st0 + q) * J.x_stride + J.x_first + wave) * (int64_t)TB) : zero;
+            rz[b][q] = (in && has_z) ? IO::template load<Act>(zb + ((st0 + q) * J.dz_stride + wave) * (int64_t)TB) : zero;
+            rx[b][q] = (in && has_x) ? IO::template load<Act>(xb + ((st0 + q) * J.x_stride + J.x_first + wave) * (int64_t)TB) : zero;
         }
     };
-    if (t0 < t1) fetch(t0);
-    int buf = 0;
-    for (int64_t st0 = t0; st0 < t1; st0 += ST, buf ^= 1) {
+    // one stage: transpose + park the register set `b`, refill it with the stage PF ahead, multiply
+    auto stage_step = [&](auto b_, int64_t st0, int buf) {
+        constexpr int b = decltype(b_)::value;
         char* stage = smem + buf * kStageBytes + lane * 16;
-        // transposition duty
 #pragma unroll
         for (int q = 0; q < ST; ++q) {
             if (has_z) {
-                const f32x16 t = tr.run(rz[q]);
+                const f32x16 t = tr.run(rz[b][q]);
                 float s = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += t[r];
                 bsum += s;
                 IO::store(stage + (q * 16 + wave) * TB, Mode::template to_act<false>(t));
             }
-            if (has_x) IO::store(stage + (q * 16 + 8 + wave) * TB, Mode::template to_act<false>(tr.run(rx[q])));
+            if (has_x) IO::store(stage + (q * 16 + 8 + wave) * TB, Mode::template to_act<false>(tr.run(rx[b][q])));
         }
-        if (st0 + ST < t1) fetch(st0 + ST);                       // next stage's saved tiles: in flight across the barrier and the MFMAs
+        if (st0 + PF * ST < t1) fetch(b_, st0 + PF * ST);         // the saved tiles PF stages ahead: in flight across the barrier and the MFMAs
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < ST; ++q) {
@@ -380,6 +385,20 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
 #pragma unroll
                 for (int i = 0; i < RT; ++i)
                     if (row0 + i < J.MT) OuterMma<Mode>::run(acc[i][j], tz[i], tx);
+            }
+        }
+    };
+    if (t0 < t1) fetch(std::integral_constant<int, 0>{}, t0);
+    if constexpr (PF == 2)
+        if (t0 + ST < t1) fetch(std::integral_constant<int, 1>{}, t0 + ST);
+    int buf = 0;
+    for (int64_t st0 = t0; st0 < t1; st0 += PF * ST) {
+        stage_step(std::integral_constant<int, 0>{}, st0, buf);
+        buf ^= 1;
+        if constexpr (PF == 2) {
+            if (st0 + ST < t1) {
+                stage_step(std::integral_constant<int, 1>{}, st0 + ST, buf);
+                buf ^= 1;
             }
         }
     }

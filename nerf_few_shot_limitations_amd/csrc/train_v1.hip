@@ -160,9 +160,13 @@ template <class Mode> constexpr int mode_of() { return NRF_MMA_F32; }
 template <> constexpr int mode_of<ModeBF16>() { return NRF_MMA_BF16; }
 template <> constexpr int mode_of<ModeF16>() { return NRF_MMA_F16; }
 
-template <class Mode, int ST>
+#ifndef NRF_WGRAD_PF
+#define NRF_WGRAD_PF 2          // stages of saved tiles in flight per wave in the 16-bit modes (train_impl.hpp:weight_grad_kernel)
+#endif
+
+template <class Mode, int ST, int PF>
 int run_weight_grad(const DeviceNet& net, const TrainDev& t, const TrainKArgs& k, float* grad, hipStream_t s, std::string& err) {
-    auto kernel = weight_grad_kernel<Mode, ST>;
+    auto kernel = weight_grad_kernel<Mode, ST, PF>;
     constexpr int kLds = 2 * ST * 16 * tile_bytes<Mode>();
     static_assert(kLds <= 160 * 1024, "weight-gradient staging exceeds the LDS");
     static unsigned char done[64] = {};
@@ -239,9 +243,9 @@ int launch_train_backward(const DeviceNet& net, const TrainDev& t, int mode, con
 
 int launch_weight_grad(const DeviceNet& net, const TrainDev& t, int mode, const TrainKArgs& k, float* grad, hipStream_t s, std::string& err) {
     switch (mode) {
-        case NRF_MMA_BF16: return run_weight_grad<ModeBF16, 2>(net, t, k, grad, s, err);
-        case NRF_MMA_F16:  return run_weight_grad<ModeF16, 2>(net, t, k, grad, s, err);
-        default:           return run_weight_grad<ModeF32, 1>(net, t, k, grad, s, err);
+        case NRF_MMA_BF16: return run_weight_grad<ModeBF16, 2, NRF_WGRAD_PF>(net, t, k, grad, s, err);
+        case NRF_MMA_F16:  return run_weight_grad<ModeF16, 2, NRF_WGRAD_PF>(net, t, k, grad, s, err);
+        default:           return run_weight_grad<ModeF32, 1, 1>(net, t, k, grad, s, err);
     }
 }
 

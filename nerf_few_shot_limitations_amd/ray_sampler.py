@@ -77,14 +77,15 @@ def hierarchical_sampling(rays_o, rays_d, z_vals, weights, N_importance, perturb
     w = L.dev_f32(weights, z.device)
     R, S = z.shape
     Ni = int(N_importance)
-    uu = None
     if u is not None:
-        uu = L.dev_f32(u, z.device).reshape(R, Ni)
+        uu, stride = L.dev_f32(u, z.device).reshape(R, Ni), Ni
     elif perturb:
-        uu = torch.rand((R, Ni), dtype=torch.float32, device=z.device)
+        uu, stride = torch.rand((R, Ni), dtype=torch.float32, device=z.device), Ni
+    else:
+        uu, stride = L.u_row(Ni, z.device), 0                        # ray_utils.py:115-116: linspace(0,1,Ni) as this host computes it
     with torch.cuda.device(z.device):
         union = torch.empty((R, S + Ni), dtype=torch.float32, device=z.device)
-        L.check(L.lib().nrf_sample_pdf(L.ptr(z), L.ptr(w), R, S, Ni, L.ptr(uu), None, L.ptr(union), L.stream_ptr()))
+        L.check(L.lib().nrf_sample_pdf(L.ptr(z), L.ptr(w), R, S, Ni, L.ptr(uu), stride, None, L.ptr(union), L.stream_ptr()))
     o = L.dev_f32(rays_o, z.device).reshape(R, 3)
     d = L.dev_f32(rays_d, z.device).reshape(R, 3)
     pts = o[:, None, :] + d[:, None, :] * union[:, :, None]
@@ -98,11 +99,11 @@ def sample_pdf(z_vals, weights, N_importance, u=None):
     w = L.dev_f32(weights, z.device)
     R, S = z.shape
     Ni = int(N_importance)
-    uu = None if u is None else L.dev_f32(u, z.device).reshape(R, Ni)
+    uu, stride = (L.u_row(Ni, z.device), 0) if u is None else (L.dev_f32(u, z.device).reshape(R, Ni), Ni)
     with torch.cuda.device(z.device):
         smp = torch.empty((R, Ni), dtype=torch.float32, device=z.device)
         union = torch.empty((R, S + Ni), dtype=torch.float32, device=z.device)
-        L.check(L.lib().nrf_sample_pdf(L.ptr(z), L.ptr(w), R, S, Ni, L.ptr(uu), L.ptr(smp), L.ptr(union), L.stream_ptr()))
+        L.check(L.lib().nrf_sample_pdf(L.ptr(z), L.ptr(w), R, S, Ni, L.ptr(uu), stride, L.ptr(smp), L.ptr(union), L.stream_ptr()))
     return smp, union
 
 

@@ -53,14 +53,15 @@ def render_rays(model: NeRFMLP, rays_o, rays_d, near, far, N_samples=64, perturb
                 ert_eps=0.0, white_bkgd=False, mma_mode: Optional[str] = None, dino=None, return_weights=True, return_z=False,
                 z_in=None):
     """Render explicit rays (R,3)/(H,W,3) -> {'rgb' (R,3), 'depth' (R,), 'weights' (R,S)[, 'z_vals' (R,S)]}.
-    Under torch.no_grad() (evaluate, train.py:294) this is ONE fused kernel launch.  With grad enabled and parameters that
-    require it (train_step, train.py:280-287) the same call returns tensors with a grad_fn: the staged training kernels behind
-    one autograd node (training.render_rays_train), so `loss.backward(); optimizer.step()` work on the drop-in unchanged."""
+    Under torch.no_grad() or with the model in eval() mode (evaluate, train.py:294-296) this is ONE fused kernel launch.  With
+    grad enabled and the model in train() mode (train_step, train.py:245,280-287) the same call returns tensors with a grad_fn:
+    the staged training kernels behind one autograd node (training.render_rays_train), so `loss.backward(); optimizer.step()`
+    work on the drop-in unchanged.  (`mma_mode` selects the arithmetic on both routes; the split mode trains in exact fp32.)"""
     L.require_gpu()
-    if model._wants_grad():
+    if model.training and model._wants_grad():
         from .training import render_rays_train
         out = render_rays_train(model, rays_o, rays_d, near, far, N_samples, perturb=perturb, t_rand=t_rand, seed=seed, lindisp=lindisp,
-                                white_bkgd=white_bkgd, dino=dino, z_in=z_in)
+                                white_bkgd=white_bkgd, dino=dino, z_in=z_in, mma_mode=mma_mode)
         if not return_weights:
             out.pop("weights")
         if not return_z:

@@ -99,10 +99,10 @@ def _grad_target(module):
     return None
 
 
-def _train_handle(module, dev):
+def _train_handle(module, dev, mma_mode=None):
     """nrf_model* with forward AND backward streams matching the current parameter values."""
     module.flat_params().ensure()
-    train_mode = L.TRAIN_MODE[module.mma_mode]
+    train_mode = L.TRAIN_MODE[mma_mode or module.mma_mode]
     h = module.handle(dev, train_mode)
     mode = L.MMA_MODES[train_mode]
     if not module._train_ready:
@@ -278,11 +278,11 @@ class _RenderFn(torch.autograd.Function):
     .grad (views of the module's flat gradient vector)."""
 
     @staticmethod
-    def forward(ctx, module, x, dirs, dino, z, d, white, *params):
+    def forward(ctx, module, x, dirs, dino, z, d, white, mma_mode, *params):
         dev = z.device
         R, S = z.shape
         n = R * S
-        h, mode = _train_handle(module, dev)
+        h, mode = _train_handle(module, dev, mma_mode)
         v1 = module.net == L.NRF_NET_V1
         lib = L.lib()
         with torch.cuda.device(dev):
@@ -324,7 +324,7 @@ class _RenderFn(torch.autograd.Function):
         def prep(g):
             return None if g is None else g.to(torch.float32).contiguous()
         g_rgb, g_depth, g_w = prep(g_rgb), prep(g_depth), prep(g_w)
-        n_in = 7
+        n_in = 8
         fp = module.flat_params()
         if g_rgb is None and g_depth is None and g_w is None:
             return (None,) * (n_in + len(fp.offsets))
@@ -354,11 +354,12 @@ _encoders = {}
 
 
 def render_rays_train(module, rays_o, rays_d, near, far, n_samples, perturb=True, t_rand=None, seed=None, lindisp=False,
-                      white_bkgd=False, dino=None, z_in=None):
+                      white_bkgd=False, dino=None, z_in=None, mma_mode=None):
     """renderer.render_rays when grad is enabled: the reference's own sequence (train.py:188-242) -- stratified samples,
     [project + fetch DINO features,] NeRFMLP, VolumeRenderer -- returning {'rgb','depth','weights','z_vals'} that carry a grad_fn.
     Gradients reach the parameters only (rays, depths and features are data: a tensor that requires grad is refused).
-    The arithmetic mode is the module's own training mode (_lib.TRAIN_MODE); early ray termination does not apply."""
+    The arithmetic mode is `mma_mode` (default: the module's own) mapped to a training mode (_lib.TRAIN_MODE: the split mode
+    trains in exact fp32); early ray termination does not apply."""
     from .ray_sampler import sample_points_along_rays
     o = L.dev_f32(L.refuse_grad(rays_o, "render_rays(rays_o)")).reshape(-1, 3)
     d = L.dev_f32(L.refuse_grad(rays_d, "render_rays(rays_d)"), o.device).reshape(-1, 3)
@@ -390,7 +391,7 @@ def render_rays_train(module, rays_o, rays_d, near, far, n_samples, perturb=True
             with torch.cuda.device(o.device):
                 L.check(L.lib().nrf_project_fetch(C.byref(dn), L.ptr(pts), R * S, L.ptr(feats), None, L.stream_ptr()))   # train.py:203-217
             del keep
-    rgb, depth, w = _RenderFn.apply(module, x, dirs, feats, z, d, int(bool(white_bkgd)), *module.flat_params().params())
+    rgb, depth, w = _RenderFn.apply(module, x, dirs, feats, z, d, int(bool(white_bkgd)), mma_mode, *module.flat_params().params())
     return {"rgb": rgb, "depth": depth, "weights": w, "z_vals": z}
 
 

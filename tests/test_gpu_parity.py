@@ -580,6 +580,31 @@ def test_rgbd_rows_equal_separate_outputs_and_work_split_is_invisible(N):
         assert torch.equal(cam[0], full["rgb"]) and torch.equal(cam[1], full["depth"])
 
 
+@pytest.mark.parametrize("mode", ["f16", "f16x3"])
+def test_every_samples_per_pass_split_gives_the_same_bits(N, mode, monkeypatch):
+    """render_kernel's rays x samples split (SPW = 1 ... 64 samples of ONE ray per wave and pass; fused_impl.hpp:pick_spw_log2) is how small
+    frames fill the chip -- BASELINE config 1 (100 x 100 x 32) runs 1250 one-pass tiles at SPW = 32 instead of 157 eight-pass tiles.
+    The split must be invisible: every pinned SPW (env NRF_SPW, read per launch) reproduces the SPW = 1 march bit for bit, with
+    weights and depths, jitter, a sample count that is no multiple of the split, and a ragged last tile."""
+    c2w = T(O.LEGO_LIKE_C2W)
+    m, _ = model_v2(N, "solid", mode)
+    H, W, S = 100, 100, 32
+    monkeypatch.setenv("NRF_SPW", "0")
+    ref = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
+    ro, rd = N.get_rays(37, 29, O.focal_for(29), c2w)                  # 1073 rays: ragged tiles at every split
+    ref2 = N.render_rays(m, ro, rd, 2.0, 6.0, 21, perturb=True, seed=5, return_z=True)
+    for l in range(1, 7):
+        monkeypatch.setenv("NRF_SPW", str(l))                          # beyond the geometry's maximum (32 columns: 5) it is clamped
+        got = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), l
+        got2 = N.render_rays(m, ro, rd, 2.0, 6.0, 21, perturb=True, seed=5, return_z=True)
+        for k in ("rgb", "depth", "weights", "z_vals"):
+            assert torch.equal(got2[k], ref2[k]), (l, k)
+    monkeypatch.delenv("NRF_SPW")
+    auto = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)  # the launcher's own choice for this frame
+    assert torch.equal(auto[0], ref[0]) and torch.equal(auto[1], ref[1])
+
+
 def test_early_ray_termination_bounds(N):
     H = W = 64; S = 64
     c2w = T(O.LEGO_LIKE_C2W)

@@ -113,23 +113,26 @@ def test_train_step_body_on_the_drop_in_render_rays(N, net):
     assert np.allclose(cpu_losses, gpu_losses, rtol=2e-4, atol=1e-6), (cpu_losses, gpu_losses)
 
 
-def test_render_rays_is_the_fused_kernel_under_no_grad_and_differentiable_otherwise(N):
-    """One call surface, two routes: no_grad -> one fused launch (no grad_fn); grad mode -> autograd node.  Same numbers
-    (fp32 mode, no jitter in eval mode) to 1e-5."""
+def test_render_rays_is_the_fused_kernel_under_no_grad_and_differentiable_in_training(N):
+    """One call surface, two routes: no_grad or eval() -> one fused launch (no grad_fn); grad mode + train() -> autograd node.
+    Same numbers (fp32 mode, jitter off on both) to 1e-5."""
     model, _ = build(N, "v2")
     c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
     ro, rd = O.get_rays(12, 12, O.focal_for(12), c2w)
     ro, rd = ro.reshape(-1, 3).cuda(), rd.reshape(-1, 3).cuda()
-    renderer = N.NeRFRenderer(model.eval(), 2.0, 6.0)
     with torch.no_grad():
-        fused = renderer.render_rays(ro, rd, 0, 32)
+        fused = N.render_rays(model, ro, rd, 2.0, 6.0, 32)
     assert fused["rgb"].grad_fn is None
-    staged = renderer.render_rays(ro, rd, 0, 32)                 # eval mode, grad enabled: differentiable, perturb off
+    assert N.render_rays(model.eval(), ro, rd, 2.0, 6.0, 32)["rgb"].grad_fn is None       # eval mode: the fused kernel, grad mode or not
+    staged = N.render_rays(model.train(), ro, rd, 2.0, 6.0, 32, perturb=False)
     assert staged["rgb"].grad_fn is not None
     for k in ("rgb", "depth", "weights"):
         assert (fused[k] - staged[k].detach()).abs().max() < 1e-5, k
     staged["depth"].sum().backward()                             # a loss on depth alone reaches the parameters too
     assert all(q.grad is not None for q in model.parameters())
+    # the arithmetic mode argument is honoured on the differentiable route as well
+    lo = N.render_rays(model, ro, rd, 2.0, 6.0, 32, perturb=False, mma_mode="bf16")
+    assert lo["rgb"].grad_fn is not None and 1e-5 < (lo["rgb"].detach() - fused["rgb"]).abs().max() < 0.2
     # rays that require grad are refused, not silently detached
     with pytest.raises(NotImplementedError):
-        renderer.render_rays(ro.clone().requires_grad_(True), rd, 0, 32)
+        N.render_rays(model, ro.clone().requires_grad_(True), rd, 2.0, 6.0, 32)

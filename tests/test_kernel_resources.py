@@ -34,9 +34,10 @@ def test_16bit_fused_kernels_use_no_scratch_and_park_operands_in_agprs(res, kern
     assert len(ks) >= 4                                          # V1, V2, V3 (64-d), V3 (128-d)
     for name, r in ks.items():
         if "NetV3" in name:
-            # V3 carries loop-invariant per-lane values of its projection / ladder across the MLP: 11-20 spilled registers, reloaded at
-            # the head of a pass (round 2: 17-33 at dino_dim 64, 71-87 at 128, inside the MLP) -- bounded here, DESIGN.md section 7
-            assert r["vgpr_spill"] <= 24 and r["scratch"] <= 128, (name, r)
+            # V3: 2-8 spilled registers left in the renderers (one operand tile evicted at the colour branch's peak; round 2: 17-33 at
+            # dino_dim 64, 71-87 at 128), 18-20 in the staged forward -- bounded here, DESIGN.md section 7
+            lim = (20, 84) if "forward_kernel" in name else (8, 68)
+            assert r["vgpr_spill"] <= lim[0] and r["scratch"] <= lim[1], (name, r)
         else:
             assert r["scratch"] == 0 and r["vgpr_spill"] == 0, (name, r)
         assert r["agprs"] > 0, (name, r)                         # operand images live in the AGPR half

@@ -10,7 +10,7 @@ and on the held-out test views.  Reported per split and mode, against the scene'
 f32 (exact fp32 MFMA) stands for the reference's fp32 arithmetic here: it matches the reference's CPU output to <= 4e-5 in
 tests/test_gpu_parity.py.
 
-    python tools/trained_scene.py [--net v2|v1] [--train-mode bf16] [--epochs 200] [--views 8] [--size 128]
+    python tools/trained_scene.py [--net v2|v1|v3] [--train-mode bf16] [--epochs 200] [--views 8] [--size 128]
 """
 import argparse
 import json
@@ -46,7 +46,23 @@ def config(size, views, epochs):
             "output": {"save_dir": "unused", "val_freq": 10 ** 9, "save_freq": 10 ** 9}}
 
 
-def train_field(net, cfg, scene_dir, train_mode, seed=0, epoch_scale=1.0):
+def standin_feature_maps(images, dim=64, grid=9):
+    """(V, grid, grid, dim) feature maps for the DINO-conditioned family: the published DINOv2 weights cannot be fetched here, so each
+    view's map is a fixed random projection of its 9 x 9 average-pooled image (+ tanh): image-derived, view-consistent, deterministic.
+    They stand in for `SpatialDINOFeatures` output (dino_feature_model.py:34-112, image 128 -> 9 x 9 patches); what is probed is the
+    renderer's arithmetic on a field trained WITH a feature side channel, not the features' quality."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(1234)
+    proj = torch.randn(3, dim, generator=g) * 1.5
+    off = torch.randn(dim, generator=g) * 0.5
+    maps = []
+    for im in images:                                             # (H,W,3) on the device
+        pooled = torch.nn.functional.adaptive_avg_pool2d(im.permute(2, 0, 1)[None], grid)[0].permute(1, 2, 0)       # (grid,grid,3)
+        maps.append(torch.tanh((pooled - 0.5) @ proj.to(im.device) + off.to(im.device)))
+    return torch.stack(maps).contiguous()
+
+
+def train_field(net, cfg, scene_dir, train_mode, seed=0, epoch_scale=1.0, sigma_bias=None, v1_batch=None):
     """Train on the scene's train split; returns (model, info).  The progressive schedule's stage boundaries (epochs 50 / 100,
     train.py:249-259) scale with `epoch_scale` when fewer than the YAML's 200 epochs are run."""
     import nerf_few_shot_limitations_amd as N
@@ -58,10 +74,22 @@ def train_field(net, cfg, scene_dir, train_mode, seed=0, epoch_scale=1.0):
     images, poses, (H, W, focal) = N.load_blender_data(scene_dir, "train", img_size=cfg["data"]["resolution"])
     images = [im.permute(1, 2, 0).float().to(dev) for im in images[: cfg["data"]["num_views"]]]
     poses = [p.float() for p in poses[: cfg["data"]["num_views"]]]
-    if net == "v2":
-        model = N.model_from_config(cfg, mma_mode=train_mode)
+    dino_maps = None
+    if net in ("v2", "v3"):
+        if net == "v3":
+            dino_maps = standin_feature_maps(images)
+        model = N.model_from_config(cfg, dino_dim=64, mma_mode=train_mode)
+        head = model.density_mlp.density_head                                                # nerf_mlp.py:63: density = relu(density_head(h))
     else:
         model = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=train_mode)       # train_minimal.py:28
+        head = model.sigma_out                                                               # nerf_model.py:22 + relu in the compositor
+    if sigma_bias is not None:
+        # Live start.  Both families push their density through a ReLU: once every sample of the early 32 x 32 batches goes negative
+        # the field is dead (black frames, loss = mean(gt^2) = 0.316, no gradient) -- measured with nn.Linear's default init on 6 of 9
+        # runs of this schedule, some of which recover by chance.  A positive density bias keeps the first, large Adam steps on the
+        # live side.  A recipe of this TOOL (the reference has no such guard), not of the renderer.
+        with torch.no_grad():
+            head.bias.fill_(float(sigma_bias))
     model = model.to(dev).train()
     o = cfg["optimizer"]
     step = FusedStep(model, lr=float(o["lr"]), weight_decay=float(o["weight_decay"]), rgb_weight=1.0)
@@ -72,13 +100,15 @@ def train_field(net, cfg, scene_dir, train_mode, seed=0, epoch_scale=1.0):
     t0 = time.perf_counter()
     first = last = None
     samples = 0
+    curve = []
     for epoch in range(epochs):
         sched_epoch = int(epoch / epoch_scale)                   # which stage of the 200-epoch schedule this epoch stands for
         step.opt.lr = train_cli.lr_at(cfg, sched_epoch)
-        if net == "v2":
-            loss, n = train_cli.train_epoch(step, cfg, sched_epoch, images, poses, H, W, focal, 2.0, 6.0, gen)
+        if net in ("v2", "v3"):
+            loss, n = train_cli.train_epoch(step, cfg, sched_epoch, images, poses, H, W, focal, 2.0, 6.0, gen, dino_maps)
         else:
             Ht, Wt, S, batch = train_cli.schedule_for(cfg, sched_epoch)
+            batch = v1_batch or batch
             tot, nb, n = None, 0, 0
             for v in range(len(images)):
                 ro, rd, tgt = train_cli.view_rays(images[v], poses[v], H, W, focal, Ht, Wt)
@@ -94,14 +124,17 @@ def train_field(net, cfg, scene_dir, train_mode, seed=0, epoch_scale=1.0):
         first = loss if first is None else first
         last = loss
         samples += n
+        if epoch % max(epochs // 20, 1) == 0 or epoch == epochs - 1:
+            curve.append(round(loss, 5))
     torch.cuda.synchronize()
     info = {"net": net, "train_mode": train_mode, "epochs": epochs, "train_views": len(images), "resolution": int(H),
             "train_seconds": round(time.perf_counter() - t0, 2), "ray_samples_trained": samples,
-            "loss_first_epoch": round(first, 6), "loss_last_epoch": round(last, 6)}
-    return model.eval(), info, (H, W, focal)
+            "loss_first_epoch": round(first, 6), "loss_last_epoch": round(last, 6), "loss_curve": curve}
+    dino = None if dino_maps is None else dict(features=dino_maps[0:1], pose=poses[0], focal=focal, H=H, W=W)      # train.py:203-208: eval uses view 0's map
+    return model.eval(), info, dino
 
 
-def compare_modes(model, scene_dir, size, views, modes=MODES, n_samples=64):
+def compare_modes(model, scene_dir, size, views, modes=MODES, n_samples=64, dino=None):
     """Render the train and test views of the scene in every mode; scores against the ground-truth images."""
     import nerf_few_shot_limitations_amd as N
     out = {}
@@ -114,7 +147,7 @@ def compare_modes(model, scene_dir, size, views, modes=MODES, n_samples=64):
         res = {}
         for mode in modes:
             with torch.no_grad():
-                r = N.evaluate_views(model, poses, H, W, focal, 2.0, 6.0, n_samples, targets=None, mma_mode=mode)
+                r = N.evaluate_views(model, poses, H, W, focal, 2.0, 6.0, n_samples, targets=None, mma_mode=mode, dino=dino)
             res[mode] = (r["images"], r["depth"], N.psnr(r["images"], gt))
         ref = res["f32"] if "f32" in res else res[modes[0]]
         rec = {"views": int(gt.shape[0])}
@@ -128,24 +161,35 @@ def compare_modes(model, scene_dir, size, views, modes=MODES, n_samples=64):
     return out
 
 
-def run(net="v2", train_mode="bf16", epochs=200, views=8, size=128, test_views=4, seed=0, modes=MODES):
+def run(net="v2", train_mode="bf16", epochs=200, views=8, size=128, test_views=4, seed=0, modes=MODES, sigma_bias=0.5, v1_batch=None, lr=None):
     """Generate the scene, train, compare: the dict bench.py reports as parity.trained_scene and the GPU test asserts on."""
     with tempfile.TemporaryDirectory() as tmp:
         scene = os.path.join(tmp, "scene")
         synthetic_scene.write_scene(scene, size=size, n_train=views, n_test=test_views)
         cfg = config(size, views, epochs)
-        model, info, _ = train_field(net, cfg, scene, train_mode, seed, epoch_scale=epochs / 200.0)
-        info.update(compare_modes(model, scene, size, views, modes))
+        if net == "v3":                                           # experiments/dino_nerf.yaml's model block
+            cfg["model"]["use_dino"] = True
+            cfg["nerf_model"]["pos_freq"] = 12
+        if lr is not None:
+            cfg["optimizer"]["lr"] = float(lr)
+        model, info, dino = train_field(net, cfg, scene, train_mode, seed, epoch_scale=epochs / 200.0, sigma_bias=sigma_bias, v1_batch=v1_batch)
+        info.update(compare_modes(model, scene, size, views, modes, dino=dino))
+        if dino is not None:
+            info["feature_maps"] = "stand-in: fixed random projection of the 9x9 average-pooled view (DINOv2 weights unavailable offline)"
         info["ground_truth"] = "analytic ray casting of tools/synthetic_scene.py (3x3 supersampled), 8-bit PNGs"
     return info
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--net", default="v2", choices=["v1", "v2"])
+    ap.add_argument("--net", default="v2", choices=["v1", "v2", "v3"])
     ap.add_argument("--train-mode", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--epochs", type=int, default=200)
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--sigma-bias", type=float, default=0.5, help="initial density bias (live start); a negative value keeps nn.Linear's default")
+    ap.add_argument("--v1-batch", type=int, default=None)
+    ap.add_argument("--lr", type=float, default=None)
+    ap.add_argument("--seed", type=int, default=0)
     a = ap.parse_args()
-    print(json.dumps(run(a.net, a.train_mode, a.epochs, a.views, a.size)))
+    print(json.dumps(run(a.net, a.train_mode, a.epochs, a.views, a.size, seed=a.seed, sigma_bias=None if a.sigma_bias < 0 else a.sigma_bias, v1_batch=a.v1_batch, lr=a.lr)))

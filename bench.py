@@ -293,15 +293,14 @@ def main(argv=None):
     # HBM bytes per launch come from PMC counters, which bench.py cannot collect itself: a STATIC figure read from the
     # committed rocprofv3 summary of this very workload (profiles/), else null
     traffic, traffic_src = None, None
-    if (args.net, args.mode, H, W, S, world, args.scaling) == ("v1", "bf16", 800, 800, 64, 1, "weak"):
-        for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
-            try:
-                with open(os.path.join(ROOT, "profiles", name)) as f:
-                    traffic = json.load(f)["derived"]["hbm_bytes_per_launch"]
-                traffic_src = f"static (profiled offline): profiles/{name} (FETCH_SIZE*2 + WRITE_SIZE, bytes per launch)"
-                break
-            except (OSError, KeyError, ValueError):
-                continue
+    if (H, W, S, world, args.scaling, args.scene, args.ert) == (800, 800, 64, 1, "weak", "solid", 0.0):
+        name = f"r03_pmc_{args.net}_{args.mode}_summary.json"          # tools/pmc_target.sh of this very workload (one 800x800x64 launch)
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                traffic = json.load(f)["kernels"][0]["derived"]["hbm_bytes_per_launch"]
+            traffic_src = f"static (profiled offline): profiles/{name} (FETCH_SIZE*2 + WRITE_SIZE, bytes per launch)"
+        except (OSError, KeyError, ValueError, IndexError):
+            pass
 
     out = {
         "metric": "M ray-samples/sec (sample+MLP+composite) at 800^2x64",
@@ -374,7 +373,7 @@ def main(argv=None):
                          "meets_1e-4": bool(float((rgb_m.cpu() - ref["rgb"]).abs().max()) <= 1e-4 and float((depth_m.cpu() - ref["depth"]).abs().max()) <= 1e-4),
                          "meets_0.01dB": bool(abs(O.psnr(rgb_m.cpu(), gt) - ps_ref) <= 0.01)}
         out["parity"] = par
-        if not args.no_trained_scene and args.net in ("v1", "v2"):
+        if not args.no_trained_scene:
             # PSNR delta of every mode on a TRAINED field (tools/trained_scene.py): a generated Blender-format scene, baseline.yaml's
             # schedule through the HIP training path, the same weights rendered in every mode against the ground-truth images
             sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -68,10 +68,11 @@ def _obj_fresh(obj: str, cmd_key: str) -> bool:
     return all(os.path.exists(p) and os.path.getmtime(p) <= t for p in files)
 
 
-def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, obj_dir: str = OBJ, fused_only: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB, obj_dir: str = OBJ, fused_only: bool = False, only=None) -> str:
     """Compile (what is stale) and return the path of libnerfhip.so.  `extra_flags`/`out`/`obj_dir` build a tuning variant
     beside the product (loaded with NRF_LIB=<path> for same-box A/B runs); `fused_only` recompiles only the fused
-    renderer / forward objects with the extra flags and reuses the product build's other objects."""
+    renderer / forward objects with the extra flags and reuses the product build's other objects; `only` = the object names
+    (e.g. {"train_v1"}) to recompile instead."""
     deps = _deps()
     # fast path (and the only one on the GPU box, where the object directory does not travel): the library is newer than every
     # source, header and this file
@@ -82,12 +83,13 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     def one(item):
         src, name, flags = item
         obj = os.path.join(obj_dir, name + ".o")
-        if fused_only and item not in FUSED:
+        if (fused_only and item not in FUSED) or (only is not None and name not in only):
             # a variant that recompiles only the fused kernels links the PRODUCT build's other objects: they must exist and be
             # newer than every source (else the A/B would silently compare against stale code)
             prod = os.path.join(OBJ, name + ".o")
-            if not os.path.exists(prod) or os.path.getmtime(prod) < _newest([d for d in deps if d != os.path.abspath(__file__)]):
-                raise RuntimeError(f"--fused-only: product object {prod} is missing or older than the sources; run the plain build first")
+            prod_cmd = " ".join([hipcc(), *FLAGS, *flags, "-MD", "-MF", prod + ".d", "-c", os.path.join(CSRC, src), "-o", prod])
+            if not _obj_fresh(prod, prod_cmd):
+                raise RuntimeError(f"variant build: product object {prod} is missing or older than a file it was built from; run the plain build first")
             shutil.copyfile(prod, obj)
             return obj, False
         cmd = [hipcc(), *FLAGS, *flags, *extra_flags, "-MD", "-MF", obj + ".d", "-c", os.path.join(CSRC, src), "-o", obj]
@@ -151,13 +153,14 @@ def kernel_resources(obj_dir: str = OBJ):
 
 
 if __name__ == "__main__":
-    # python -m nerf_few_shot_limitations_amd.build [--force] [--variant NAME [--fused-only] -DNRF_PREFETCH=6 ...]
+    # python -m nerf_few_shot_limitations_amd.build [--force] [--variant NAME [--fused-only | --only train_v1,...] -DNRF_PREFETCH=6 ...]
     argv = sys.argv[1:]
     if "--variant" in argv:
         name = argv[argv.index("--variant") + 1]
         flags = [a for a in argv if a.startswith("-D")]
+        only = set(argv[argv.index("--only") + 1].split(",")) if "--only" in argv else None
         path = build(force=True, verbose=False, extra_flags=flags, out=os.path.join(PKG, f"libnerfhip_{name}.so"),
-                     obj_dir=os.path.join(PKG, "build", name), fused_only="--fused-only" in argv)
+                     obj_dir=os.path.join(PKG, "build", name), fused_only="--fused-only" in argv, only=only)
     else:
         path = build(force="--force" in argv, verbose=True)
     print(path)

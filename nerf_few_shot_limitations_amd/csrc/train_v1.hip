@@ -161,7 +161,7 @@ template <> constexpr int mode_of<ModeBF16>() { return NRF_MMA_BF16; }
 template <> constexpr int mode_of<ModeF16>() { return NRF_MMA_F16; }
 
 #ifndef NRF_WGRAD_PF
-#define NRF_WGRAD_PF 2          // stages of saved tiles in flight per wave in the 16-bit modes (train_impl.hpp:weight_grad_kernel)
+#define NRF_WGRAD_PF 1          // stages of saved tiles in flight per wave (train_impl.hpp:weight_grad_kernel); 2 measured equal (profiles/r03_ab_wgrad_prefetch.txt)
 #endif
 
 template <class Mode, int ST, int PF>

@@ -130,7 +130,9 @@ def train_field(net, cfg, scene_dir, train_mode, seed=0, epoch_scale=1.0, sigma_
     info = {"net": net, "train_mode": train_mode, "epochs": epochs, "train_views": len(images), "resolution": int(H),
             "train_seconds": round(time.perf_counter() - t0, 2), "ray_samples_trained": samples,
             "loss_first_epoch": round(first, 6), "loss_last_epoch": round(last, 6), "loss_curve": curve}
-    dino = None if dino_maps is None else dict(features=dino_maps[0:1], pose=poses[0], focal=focal, H=H, W=W)      # train.py:203-208: eval uses view 0's map
+    # the side channel of each training view (its own map + camera: what the field was trained with, train.py:203-206) and the one the
+    # reference's evaluate() uses for every test view (view 0's, train.py:207-208)
+    dino = None if dino_maps is None else [dict(features=dino_maps[v:v + 1], pose=poses[v], focal=focal, H=H, W=W) for v in range(len(poses))]
     return model.eval(), info, dino
 
 
@@ -147,8 +149,15 @@ def compare_modes(model, scene_dir, size, views, modes=MODES, n_samples=64, dino
         res = {}
         for mode in modes:
             with torch.no_grad():
-                r = N.evaluate_views(model, poses, H, W, focal, 2.0, 6.0, n_samples, targets=None, mma_mode=mode, dino=dino)
-            res[mode] = (r["images"], r["depth"], N.psnr(r["images"], gt))
+                if dino is None:
+                    r = N.evaluate_views(model, poses, H, W, focal, 2.0, 6.0, n_samples, targets=None, mma_mode=mode)
+                    img, dep = r["images"], r["depth"]
+                else:
+                    # train views: each with its own feature map (as trained); test views: view 0's map, as the reference evaluates
+                    per = [N.evaluate_views(model, poses[v:v + 1], H, W, focal, 2.0, 6.0, n_samples, targets=None, mma_mode=mode,
+                                            dino=dino[v] if split == "train" else dino[0]) for v in range(poses.shape[0])]
+                    img, dep = torch.cat([x["images"] for x in per]), torch.cat([x["depth"] for x in per])
+            res[mode] = (img, dep, N.psnr(img, gt))
         ref = res["f32"] if "f32" in res else res[modes[0]]
         rec = {"views": int(gt.shape[0])}
         for mode in modes:

@@ -99,9 +99,31 @@ def training_line(N, args, dev):
         loss = step(pts, z, d, tgt, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k
-    return {"metric": "M ray-samples/s per optimisation step (forward + backward + Adam)", "value": round(R * S / dt / 1e6, 2),
-            "ms_per_step": round(dt * 1e3, 4), "rays": R, "samples_per_ray": S, "net": args.net, "dtype": mode,
-            "loss_first": round(first, 6), "loss_last": round(loss.item(), 6)}
+    out = {"metric": "M ray-samples/s per optimisation step (forward + backward + Adam)", "value": round(R * S / dt / 1e6, 2),
+           "ms_per_step": round(dt * 1e3, 4), "rays": R, "samples_per_ray": S, "net": args.net, "dtype": mode,
+           "loss_first": round(first, 6), "loss_last": round(loss.item(), 6)}
+    # the reference's UNMODIFIED train_step body (train.py:280-287) on the drop-in surface: render_rays with a grad_fn, torch's own Adam
+    rend = N.NeRFRenderer(m, 2.0, 6.0, dino_features=[torch.rand(1, 9, 9, 64, device=dev) * 2 - 1] if args.net == "v3" else None,
+                          poses=[torch.eye(4)], focal=100.0, H=128, W=128)
+    ro = torch.rand(R, 3, device=dev) - 0.5 + torch.tensor([0.0, 0.0, 4.0], device=dev)
+    opt = torch.optim.Adam(m.parameters(), lr=5e-4, weight_decay=1e-6)
+
+    def body():
+        pred = rend.render_rays(ro, d, 0, S)
+        ls = torch.nn.functional.mse_loss(pred["rgb"], tgt)
+        opt.zero_grad()
+        ls.backward()
+        opt.step()
+    for _ in range(3):
+        body()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(k):
+        body()
+    torch.cuda.synchronize()
+    out["autograd_render_rays_ms_per_step"] = round((time.perf_counter() - t0) / k * 1e3, 4)
+    out["autograd_note"] = "train.py:280-287 verbatim in shape: predictions = render_rays(...), mse, zero_grad, backward, torch.optim.Adam.step"
+    return out
 
 
 def main(argv=None):

@@ -18,7 +18,9 @@ namespace nrf {
 constexpr int kBiasMaxFloats = 4096;                                   // 16 KiB bias table
 constexpr int kLdsRing = kSlots * kChunkBytes;                         // 128 KiB
 constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64 + 4096;   // staged forward: ring + bias table (+ the renderers' vote flags and depth-ladder cache)
-constexpr int kLdsBytesQueue = kLdsBytes + 14 * 512 * 4;                // both renderers: + 14 floats of per-lane ray state for up to 512 threads
+constexpr int kLadderLds = 4096;                                        // the renderers keep the whole depth ladder in LDS (n_samples <= 4096: api.cpp:check_opts)
+constexpr int kRenderThreads = 256;                                     // both renderers run 4 waves
+constexpr int kLdsBytesQueue = kLdsRing + kBiasMaxFloats * 4 + 64 + kLadderLds * 4 + 14 * kRenderThreads * 4;   // + 14 floats of per-lane ray state
 static_assert(kLdsBytesQueue <= 160 * 1024, "renderers: LDS over budget (use a 6-slot ring)");
 
 struct NetArgs {
@@ -90,7 +92,6 @@ __device__ __forceinline__ int64_t global_ray(const RenderArgs& a, int64_t i, in
 // nothing per-ray is live across the MLP, whose register budget is full -- a compiler spill to scratch there is a VMEM
 // op whose wait drains the LDS-DMA weight queue (the round-1 V2 / V3 builds carried ~80 spilled dwords).
 enum { F_OX, F_OY, F_OZ, F_DX, F_DY, F_DZ, F_NORM, F_Z, F_T, F_R, F_G, F_B, F_DEPTH, F_ACC, kFields };
-constexpr int kLadderLds = 1024;      // depth-ladder entries cached in LDS by the ray-queue kernel (per-lane sample indices gather from it)
 constexpr int kLdsState = kLdsRing + kBiasMaxFloats * 4 + 64 + kLadderLds * 4;     // byte offset of the state rows
 
 template <class Net, class Mode, int NT, int WAVES, int LP, int LD>
@@ -115,21 +116,23 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const RenderArgs& a = P.a;
     const int S = a.n_samples;
-    // a caller-computed depth ladder is cached in LDS when it fits: the owner lane's serial composite of its SPW samples reads one
-    // depth per step, and a dependent GLOBAL load there costs ~0.6 us per sample (17 us per pass at SPW = 32: measured)
+    // The un-jittered depth ladder lives in LDS for the whole launch: the caller's table (the reference's own torch.linspace ladder) or,
+    // without one, the in-kernel formula evaluated once per sample index.  Every later lookup is one ds_read: no global load in the
+    // owner lane's composite loop, and none of the formula's wave-uniform constants (1/near, 1/far, the step) hoisted into VGPRs that
+    // the network walk would spill.
+    static_assert(WAVES * 64 <= kRenderThreads, "state rows are sized for 4 waves");
     NRF_LDS float* zl = (NRF_LDS float*)(bias + kBiasMaxFloats) + 16;
-    const bool table = a.z_ladder != nullptr;
-    const bool cached = table && S <= kLadderLds;
-    if (cached)
-        for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder[i];
+    {
+        const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, nullptr);
+        for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder ? a.z_ladder[i] : ladder_z(lad, i);
+    }
     load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
 
     Pipe<WAVES, pinned_walk<Mode, NT>()> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
-    const DepthLadder lad = make_ladder_uniform(a.near, a.far, S, a.lindisp, nullptr);
-    auto z_base = [&](int s) -> float { return cached ? zl[s] : (table ? a.z_ladder[s] : ladder_z(lad, s)); };
+    auto z_base = [&](int s) -> float { return zl[s]; };
     // Samples per ray and MLP pass (host: pick_spw_log2).  The wave's COLS sample columns are RPW = COLS/SPW rays x SPW consecutive
     // samples: column q = ray (q mod RPW), sample (pass*SPW + q div RPW).  A ray is still composited front to back by ONE lane
     // (lane L < RPW owns ray L of the wave; its state rows are the ones of thread L), which fetches the other columns' network
@@ -249,11 +252,30 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                     pt[1] = point_on_ray(SQ(n, F_OY), SQ(n, F_DY), zc);
                     pt[2] = point_on_ray(SQ(n, F_OZ), SQ(n, F_DZ), zc);
                     Act e1[KT0];
+#ifdef NRF_ABLATE_BUILD
+                    // timing experiments on V3 (results are wrong): 64 = the second fusion pass reuses un-gated first-layer tiles of the
+                    // sample position instead of re-encoding; 32 = no feature-map gather (a constant map, no global loads)
+                    if (PASS == 1 && (P.net.ablate & 64)) {
+                        Act c1[pe_tiles(1)];
+                        encode3<Mode, 1>(pt, h, c1, w0[n]);
+#pragma unroll
+                        for (int t = 0; t < KT0; ++t) e1[t] = c1[0];
+                    } else
+#endif
                     encode3<Mode, LP>(pt, h, e1, w0[n]);
 #pragma unroll
                     for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                     if constexpr (Net::kDino) {
                         constexpr int DT = Net::KT0 - KT0;
+#ifdef NRF_ABLATE_BUILD
+                        if (PASS == 0 && (P.net.ablate & 32)) {
+                            DinoTaps tp;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { tp.off[k] = 0; tp.w[k] = 0.25f; }
+                            if (P.net.ablate & 128) held[n].gather(a.dino.features, tp, h);      // 128: keep the loads, one L2-hot address
+                            else { tp.off[0] = tp.off[1] = tp.off[2] = tp.off[3] = -1; held[n].gather(a.dino.features, tp, h); }
+                        } else
+#endif
                         if constexpr (PASS == 0) held[n].gather(a.dino.features, dino_taps(a.dino, pt), h);
                         Act dt[DT];
                         held[n].template tiles<PASS>(w1[n], dt);
@@ -405,10 +427,11 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const RenderArgs& a = P.a;
     const int S = a.n_samples;
-    const bool table = a.z_ladder != nullptr;             // a caller-computed ladder: cached in LDS when it fits
-    const bool cached = table && S <= kLadderLds;
-    if (cached)
-        for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder[i];
+    static_assert(WAVES * 64 <= kRenderThreads, "state rows are sized for 4 waves");
+    {   // the depth ladder in LDS: the caller's table or the in-kernel formula, once per sample index (render_kernel)
+        const DepthLadder lad = make_ladder(a.near, a.far, S, a.lindisp, nullptr);
+        for (int i = threadIdx.x; i < S; i += blockDim.x) zl[i] = a.z_ladder ? a.z_ladder[i] : ladder_z(lad, i);
+    }
     ST(F_OX) = 0.f; ST(F_OY) = 0.f; ST(F_OZ) = 0.f; ST(F_DX) = 0.f; ST(F_DY) = 0.f; ST(F_DZ) = -1.f; ST(F_Z) = 1.f;
     load_bias_table(bias, P.net.bias, P.net.n_bias);      // ends with __syncthreads()
 
@@ -416,8 +439,7 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
 
-    const DepthLadder lad = make_ladder_uniform(a.near, a.far, S, a.lindisp, nullptr);
-    auto z_base = [&](int s) -> float { return cached ? zl[s] : (table ? a.z_ladder[s] : ladder_z(lad, s)); };
+    auto z_base = [&](int s) -> float { return zl[s]; };
     auto z_of = [&](int64_t ray, int s) -> float {
         if (a.z_in) return a.z_in[ray * S + s];
         if (!a.perturb) return z_base(s);

@@ -100,7 +100,12 @@ inline bool fill_slots(const TrainDev& t, int mode, int64_t n, TrainKArgs& k, st
 // Geometry of the chain kernels: 8 waves x 32 samples per workgroup (two waves per SIMD) is the throughput shape; a batch
 // that does not even give every CU one such workgroup runs 4 waves x 32 instead (twice the workgroups, one wave per SIMD:
 // the pass of a lone wave is latency, not throughput, and the reference's last schedule stage is 512 rays x 64 samples).
-inline bool small_batch(const DeviceNet& net, int64_t n) { return tiles32(n) / 4 <= net.cu_count; }
+inline bool small_batch(const DeviceNet& net, int64_t n) {
+    static const int forced = [] { const char* e = getenv("NRF_TRAIN_WAVES"); return e ? atoi(e) : 0; }();      // A/B runs: 4 or 8
+    if (forced == 4) return true;
+    if (forced == 8) return false;
+    return tiles32(n) / 4 <= net.cu_count;
+}
 
 inline bool check_train_common(const DeviceNet& net, const TrainDev& t, int mode, std::string& err) {
     if (mode < 0 || mode > 2) { err = "unknown mma_mode"; return false; }

@@ -1,5 +1,5 @@
 """python -m nerf_few_shot_limitations_amd.train_cli --config experiments/baseline.yaml --data data/nerf_synthetic/lego \\
-        [--epochs N] [--mode bf16|f16|f32] [--out DIR] [--checkpoint CKPT] [--dino-weights DIR | --dino-maps maps.pt] [--seed 0]
+        [--epochs N] [--mode bf16|f16|f32] [--eval-mode f16] [--out DIR] [--checkpoint CKPT] [--dino-weights DIR | --dino-maps maps.pt] [--seed 0]
 
 The training run of `NeRFDINOTrainer` (src/training/train.py:244-292 `train_step`, :344-372 `train`) as a command on the
 HIP path: the YAML loads unchanged; per epoch and training view the rays are cast at the progressive schedule's
@@ -151,7 +151,10 @@ def main(argv=None):
     ap.add_argument("--config", required=True)
     ap.add_argument("--data", required=True, help="dataset directory holding transforms_train.json / transforms_test.json")
     ap.add_argument("--epochs", type=int, default=None, help="default: training.epochs of the config")
-    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--mode", default="bf16", choices=["bf16", "f16", "f32"],
+                    help="arithmetic of the TRAINING kernels (bf16: its exponent range suits the unscaled gradients)")
+    ap.add_argument("--eval-mode", default="f16", choices=["bf16", "f16", "f16x3", "f32"],
+                    help="arithmetic of the validation renders: f16 keeps the reported PSNR within 0.01 dB of an fp32 render (bf16 does not)")
     ap.add_argument("--out", default=None, help="default: output.save_dir of the config")
     ap.add_argument("--checkpoint", default=None, help="resume from this file: weights, Adam moments / step, epoch and best PSNR")
     ap.add_argument("--dino-maps", default=None, help="precomputed feature maps (V,Hp,Wp,C), torch.save'd, one per training view")
@@ -233,7 +236,7 @@ def main(argv=None):
             continue
         if (epoch + 1) % int(cfg["output"]["val_freq"]) == 0 or epoch + 1 == epochs:
             m = evaluate_views(model, test_poses, H, W, focal, rs["near"], rs["far"], rs["n_samples"], targets=targets, white_bkgd=rs["white_bkgd"],
-                               mma_mode=args.mode, dino=eval_dino, out_dir=os.path.join(out_dir, f"val_{epoch + 1}"))
+                               mma_mode=args.eval_mode, dino=eval_dino, out_dir=os.path.join(out_dir, f"val_{epoch + 1}"))
             model.train()
             rec.update(psnr=m["psnr"], ssim=m["ssim"])
             if m["psnr"] > best:

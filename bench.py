@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- M ray-samples/s of the fused sample+encode+MLP+composite renderer.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU, RCCL)
+    python bench.py --gpus N --steps K --warmup W          (N>1: one rank per GPU over RCCL -- under torch.distributed.run, or
+                                                            self-launched: with no launcher in the environment this command starts
+                                                            its own N ranks as fresh child processes)
 
 Workload (BASELINE.json metric): synthetic 800x800 camera frames, 64 samples per ray, the 8x256
 NeRF MLP (nerf_model.NeRFMLP, 951 808 FLOP per ray-sample), deterministic random-init weights
-("solid" scene; early ray termination OFF, so every one of the R*S samples is evaluated), bf16 MFMA.
+("solid" scene; early ray termination OFF, so every one of the R*S samples is evaluated), f16 MFMA (HEADLINE_MODE: the
+fastest mode whose PSNR stays within 0.01 dB of the fp32 render -- asserted by tests/test_gpu_trained_scene.py; --mode bf16 | f16x3 | f32).
 
 --scaling weak (default): one step renders n_gpus views of the sensor: every view's rays are cut into 16-row pixel tiles
 dealt round-robin over the ranks, so per-GPU work is one frame's worth of rays whatever N is; each rank renders its
@@ -22,7 +25,9 @@ The JSON line also carries
   cpu_baseline -- the CPU oracle (oracle/nerf_oracle.py, a port of the reference's PyTorch CPU path) timed on a band of
                   rows of the same frame on this host's cores;
   parity       -- max abs error / PSNR of every arithmetic mode vs that oracle band, and the PSNR delta against a common
-                  ground truth (the band marched with 2x the samples);
+                  ground truth (the band marched with 2x the samples); parity.trained_scene: a field trained in this run on a
+                  generated Blender-format scene (tools/trained_scene.py), every mode's PSNR against the ground-truth images;
+                  parity.headline_mode: whether the mode of `value` meets the 0.01 dB bar on both;
   parity_mode  -- the parity-grade fast mode (f16x3: split-f16, 3 MFMAs per product): ms per frame, TFLOP/s credited 1x,
                   fraction of the 2.5 PFLOP/s peak -- the mode that meets the 1e-4 / 0.01 dB bars -- beside f16 and f32;
   ert          -- early ray termination on the "smooth" scene: ms, speed-up, max |d rgb| vs the full march (must be <= eps).

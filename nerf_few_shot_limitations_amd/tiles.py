@@ -124,18 +124,20 @@ class TileJob:
         even = self.n_real == self.per_rank
         step = self.views_per_launch
         seed0 = int(self.opts.rng_seed)
-        with torch.cuda.device(self.device):
-            for v0 in range(0, self.V, step):
-                nv = min(step, self.V - v0)
-                sub = (C.c_float * (12 * nv)).from_buffer(self.poses, 4 * 12 * v0)
-                out = self.buf[v0:v0 + nv] if even else self.buf[v0, :n]
-                # the kernel keys a view's jitter by seed + (camera index inside the launch) * 0x51ED27: offset the seed by the
-                # launch's first view so that the pattern is a function of the GLOBAL view index, however the views are batched
-                self.opts.rng_seed = (seed0 + v0 * 0x51ED27) & 0xFFFFFFFFFFFFFFFF
-                L.check(L.lib().nrf_render_cameras_tiles(h, self.H, self.W, self.focal, C.cast(sub, C.c_void_p), nv, self.tile_rays,
-                                                         self.rank, self.world, self.n_real, C.byref(self.opts),
-                                                         L.ptr(out), None, None, None, L.stream_ptr()))
-        self.opts.rng_seed = seed0
+        try:
+            with torch.cuda.device(self.device):
+                for v0 in range(0, self.V, step):
+                    nv = min(step, self.V - v0)
+                    sub = (C.c_float * (12 * nv)).from_buffer(self.poses, 4 * 12 * v0)
+                    out = self.buf[v0:v0 + nv] if even else self.buf[v0, :n]
+                    # the kernel keys a view's jitter by seed + (camera index inside the launch) * 0x51ED27: offset the seed by the
+                    # launch's first view so that the pattern is a function of the GLOBAL view index, however the views are batched
+                    self.opts.rng_seed = (seed0 + v0 * 0x51ED27) & 0xFFFFFFFFFFFFFFFF
+                    L.check(L.lib().nrf_render_cameras_tiles(h, self.H, self.W, self.focal, C.cast(sub, C.c_void_p), nv, self.tile_rays,
+                                                             self.rank, self.world, self.n_real, C.byref(self.opts),
+                                                             L.ptr(out), None, None, None, L.stream_ptr()))
+        finally:
+            self.opts.rng_seed = seed0
 
     def pack(self):
         """The gather buffer (kept for callers of the round-1 interface: the kernel has already written it)."""

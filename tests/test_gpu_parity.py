@@ -605,6 +605,30 @@ def test_every_samples_per_pass_split_gives_the_same_bits(N, mode, monkeypatch):
     assert torch.equal(auto[0], ref[0]) and torch.equal(auto[1], ref[1])
 
 
+def test_tile_jobs_key_the_jitter_by_the_global_view_index(N):
+    """with perturb on, a view's stratified pattern must not depend on how its launch was batched.  5 two-row tiles over 2
+    ranks: rank 0 (3 real tiles = its share: ONE launch of 3 views) and rank 1 (2 real + 1 padding: one launch PER view) both
+    reproduce, view by view, the single-view render under seed + v * 0x51ED27 -- the key the kernel gives view v of a batch."""
+    from nerf_few_shot_limitations_amd import tiles
+    c2w = T(O.LEGO_LIKE_C2W)
+    poses = torch.stack([c2w, c2w.clone(), c2w.clone()])
+    poses[1, 0, 3] += 0.2
+    poses[2, 1, 3] -= 0.3
+    H, W, S, seed = 10, 16, 12, 777
+    m, _ = model_v1(N, "solid", "f16")
+    tile_rays = 2 * W
+    for rank in (0, 1):
+        job = tiles.TileJob(m, H, W, O.focal_for(W), poses, 2.0, 6.0, S, rank, 2, tile_rays, perturb=True, seed=seed)
+        assert job.launches_per_step == (1 if rank == 0 else 3) and job.rays_per_step == 3 * job.n_real * tile_rays
+        job.launch()
+        ids = tiles.local_ray_ids(rank, 2, H * W, tile_rays)[: job.n_real * tile_rays]
+        for v in range(3):
+            rgb, depth = N.render_camera(m, H, W, O.focal_for(W), poses[v], 2.0, 6.0, S, perturb=True, seed=seed + v * 0x51ED27)
+            got = job.buf[v, : job.n_real * tile_rays]
+            assert torch.equal(got[:, :3], rgb[ids.cuda()]) and torch.equal(got[:, 3], depth[ids.cuda()]), (rank, v)
+        assert int(job.opts.rng_seed) == seed                       # the per-launch offset does not leak into the job
+
+
 def test_early_ray_termination_bounds(N):
     H = W = 64; S = 64
     c2w = T(O.LEGO_LIKE_C2W)

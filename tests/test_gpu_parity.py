@@ -916,6 +916,43 @@ def test_empty_and_bad_arguments(N):
     assert maxdiff(out["rgb"], ref["rgb"]) <= TOL
 
 
+@pytest.mark.parametrize("pmode", PARITY)
+def test_maximum_sample_count_and_in_kernel_ladders(N, pmode):
+    """The renderers keep the whole depth ladder in LDS (fused_impl.hpp: kLadderLds = 4096 = the ABI's maximum n_samples).
+    (a) S = 4096 fills that carve-out to the last entry: a few rays against the oracle, with and without jitter.
+    (b) A C caller may pass no ladder at all (nrf_render_opts.z_ladder = NULL): the kernel then evaluates the scalar torch.linspace
+    formula once per sample index -- depth and disparity spacing -- which must reproduce the oracle's ladder to one ulp-amplified bound
+    (the Python surface always hands the host's own ladder over, so this path is reached through the C ABI only)."""
+    import ctypes as C
+    from nerf_few_shot_limitations_amd import _lib as L
+    from nerf_few_shot_limitations_amd.renderer import _opts
+    m, p = model_v1(N, "solid", pmode)
+    c2w = T(O.LEGO_LIKE_C2W)
+    ro, rd = O.get_rays(6, 5, O.focal_for(5), c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    S = 4096
+    tr = torch.from_numpy(O.uniform01(77, 30 * S).reshape(30, S)).float()
+    for t_rand in (None, tr):
+        out = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=t_rand, return_z=True)
+        ref = O.render_rays(p, "v1", ro, rd, 2.0, 6.0, S, t_rand=t_rand)
+        assert maxdiff(out["z_vals"], ref["z_vals"]) <= 1e-6
+        assert maxdiff(out["rgb"], ref["rgb"]) <= TOL and maxdiff(out["depth"], ref["depth"]) <= 5 * TOL       # 4096 terms in the depth sum
+    # (b) no caller ladder: the in-kernel formula, both spacings, fused and ray-queue kernels
+    dev = torch.device("cuda", torch.cuda.current_device())
+    o, d = ro.cuda().contiguous(), rd.cuda().contiguous()
+    h = m.handle(dev, pmode)
+    for lindisp in (False, True):
+        for S2, eps in ((64, 0.0), (64, 1e-30), (37, 0.0)):
+            opts = _opts(2.0, 6.0, S2, False, None, 0, lindisp, eps, False, pmode, None, dev)
+            opts.z_ladder = None
+            rgb = torch.empty((30, 3), device=dev); depth = torch.empty((30,), device=dev); z = torch.empty((30, S2), device=dev)
+            L.check(L.lib().nrf_render_rays(h, L.ptr(o), L.ptr(d), 30, C.byref(opts), L.ptr(rgb), L.ptr(depth), None, L.ptr(z), L.stream_ptr()))
+            zref = O.z_steps(2.0, 6.0, S2, lindisp).expand(30, S2)
+            assert maxdiff(z, zref) <= 1e-6, (lindisp, S2, eps)
+            ref = O.render_rays(p, "v1", ro, rd, 2.0, 6.0, S2, z_in=z.cpu())          # on the kernel's own ladder: the encoding amplifies an ulp of depth
+            assert maxdiff(rgb, ref["rgb"]) <= TOL and maxdiff(depth, ref["depth"]) <= TOL, (lindisp, S2, eps)
+
+
 # ------------------------------------------------------------------ a3 hierarchical resampling (parity UNPINNED: vs our oracle only)
 def test_sample_pdf_vs_oracle(N):
     R, S, Ni = 333, 64, 32

@@ -136,3 +136,24 @@ def test_render_rays_is_the_fused_kernel_under_no_grad_and_differentiable_in_tra
     # rays that require grad are refused, not silently detached
     with pytest.raises(NotImplementedError):
         N.render_rays(model, ro.clone().requires_grad_(True), rd, 2.0, 6.0, 32)
+
+
+def test_differentiable_route_takes_empty_and_single_sample_batches(N):
+    model, p = build(N, "v2")
+    r = N.render_rays(model, torch.zeros(0, 3).cuda(), torch.zeros(0, 3).cuda(), 2.0, 6.0, 8)
+    assert r["rgb"].shape == (0, 3) and r["weights"].shape == (0, 8)
+    # one sample per ray: the 1e10 tail rule alone (nerf_mlp.py:182) -- alpha is a STEP function of the density there, so the comparison
+    # is made on rays whose density is clearly positive (a density of +-1e-7 flips the pixel on either side of any comparison)
+    c2w = torch.from_numpy(O.LEGO_LIKE_C2W.copy())
+    ro, rd = O.get_rays(16, 16, O.focal_for(16), c2w)
+    ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+    r = N.render_rays(model, ro.cuda(), rd.cuda(), 2.0, 6.0, 1, perturb=False)
+    ref = O.render_rays(p, "v2", ro, rd, 2.0, 6.0, 1)
+    pts = ro + rd * 2.0
+    dens = O.mlp_v2({k: v for k, v in p.items()}, pts, rd)[1][:, 0]
+    clear = dens > 1e-3
+    assert int(clear.sum()) >= 10
+    assert (r["rgb"].detach().cpu() - ref["rgb"])[clear].abs().max() < 1e-5
+    assert torch.isfinite(r["rgb"]).all()
+    r["rgb"].sum().backward()
+    assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in model.parameters())

@@ -5,6 +5,8 @@
 #include "feature_map.hpp"
 #include "mlp_core.hpp"
 
+#include <type_traits>
+
 namespace nrf {
 
 // 1/(2 pi) split in two floats for an exact-ish turn count: rev = x*C_HI (+ error term)
@@ -377,12 +379,22 @@ __device__ __forceinline__ void dino_scaled_tiles(const float (&e)[16 * DT], flo
 
 // What a column of the fused V3 renderer keeps of its gathered feature-map channels between NetV3's two fusion passes (the
 // gather -- two rounds of global loads whose latency a lone wave cannot cover -- happens once per sample).
-//   * fp32-class modes (Act = 16 registers per tile): the blended fp32 channels, 16 DT registers; both passes are exact.
-//   * 16-bit modes: the FIRST pass's own operand tiles (the channels rounded to 16 bits, 8 DT registers: half the hold --
-//     with fp32 channels the dino_dim-128 kernels spilled 71-87 VGPRs, the dino_dim-64 ones 17-33).  The second pass
-//     rescales THOSE by the gate: round16(round16(e) * w1) instead of round16(e * w1) -- one more 16-bit rounding of an input
-//     (<= 2^-11 relative in f16, 2^-8 in bf16: the size of the operand rounding that follows it anyway).
-template <class Mode, int DT, bool PACKED = (sizeof(typename Mode::Act) == 32)>
+//   * default: the blended fp32 channels, 16 DT registers per operand tile; both passes round them once, exactly as the
+//     reference's arithmetic does (round16(e * w1)).
+//   * f16 at dino_dim 128 (DT = 4) only: the FIRST pass's own operand tiles (the channels rounded to 16 bits, 8 DT registers: half
+//     the hold); the second pass rescales THOSE by the gate: round16(round16(e) * w1), one more rounding of an input (<= 2^-11
+//     relative).  With fp32 channels that kernel spills 53 registers inside the MLP, with the packed hold 4.  Measured before
+//     choosing (profiles/r03_ab_v3_hold.txt): at dino_dim 64 the two holds run at the same speed (57.0 ms either way) once the
+//     other spill sources are gone, f16 loses 0.2 dB of its 87 dB against the oracle -- and bf16 loses 24 dB (70.8 -> 46.7 dB, max
+//     rgb error 0.009 -> 0.85: a second 2^-8 rounding in front of the softmax gate), so bf16 never holds packed.
+#ifndef NRF_DINO_HOLD_F32
+#define NRF_DINO_HOLD_F32 0      // 1 (A/B builds): every mode holds fp32 channels
+#endif
+#ifndef NRF_DINO_HOLD_PACKED
+#define NRF_DINO_HOLD_PACKED 0   // 1 (A/B builds): both 16-bit modes hold packed tiles at every width (the first round-3 build)
+#endif
+template <class Mode, int DT, bool PACKED = (sizeof(typename Mode::Act) == 32 && !NRF_DINO_HOLD_F32 &&
+                                              (NRF_DINO_HOLD_PACKED || (std::is_same<Mode, ModeF16>::value && DT > 2)))>
 struct DinoHeld {
     float e[16 * DT];
     __device__ __forceinline__ void gather(const float* __restrict__ feat, const DinoTaps& tp, int h) { dino_blend<DT>(feat, tp, h, e); }

@@ -6,8 +6,9 @@ PSNR = -10 log10(mse), data range 1 (train_multiscale.py:294-295).  SSIM follows
 instantiates, `torchmetrics.StructuralSimilarityIndexMeasure()` with its defaults (train.py:100,328): single scale, 11x11
 Gaussian window of sigma 1.5, K1=.01, K2=.03, reflect-padded inputs, the padded border cropped from the index map before the
 mean, and -- because the reference passes no data_range -- the range taken from the data, max(pred range, target range).
-`ssim(..., data_range=1.0, crop_border=False)` gives the textbook form.  torchmetrics is not importable here, so parity with it is
-unpinned; tests/test_host_glue.py checks this code against an independent scipy restatement of the same definition.  LPIPS
+`ssim(..., data_range=1.0, crop_border=False)` gives the textbook form.  torchmetrics is not importable here; tests/test_host_glue.py
+checks this code against an independent scipy restatement of the same definition and against the one known answer available
+offline, the library's own docstring example (uniform noise vs 0.75 x itself, data_range 1: 0.9219).  LPIPS
 needs VGG weights that cannot be fetched offline and is not provided.
 """
 from __future__ import annotations

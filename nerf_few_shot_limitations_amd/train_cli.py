@@ -166,14 +166,20 @@ def main(argv=None):
     ap.add_argument("--data-parallel", action="store_true",
                     help="launched with torch.distributed.run, one process per GPU: ray batches shard over the ranks, one all-reduce of the "
                          "flat gradient vector per step (RCCL); rank 0 validates and writes")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="--data-parallel on a box with ONE GPU: every rank on cuda:0, the gradient all-reduce over gloo through host memory "
+                         "(RCCL refuses two ranks on one card); exercises the sharding and the collective, not multi-GPU speed")
     args = ap.parse_args(argv)
     rank, world = 0, 1
     if args.data_parallel:
         import torch.distributed as dist
-        local = int(os.environ.get("NERF_TRAIN_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        local = 0 if args.rehearse else int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         if not dist.is_initialized():
-            dist.init_process_group(backend=os.environ.get("NERF_TRAIN_BACKEND", "nccl"))
+            if args.rehearse:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
         rank, world = dist.get_rank(), dist.get_world_size()
 
     torch.manual_seed(args.seed)                          # parameter init (when no checkpoint is given) and the ray shuffles

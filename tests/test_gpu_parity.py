@@ -345,6 +345,21 @@ def test_split_mode_device_repack_equals_host_pack(N, golden):
         with torch.no_grad():
             b = m(x)
         assert torch.equal(a, b), mode
+        # out-of-range weights saturate at +-65504 on both packers (host: packing.cpp, device: convert_pair) instead of
+        # becoming inf (split mode: hi = inf, lo = -inf -> NaN products): finite outputs, the same bits from either route
+        big = {k: v.clone() for k, v in O.make_weights("v1", 0, "fog").items()}
+        big["layers.2.weight"][3, 4] = 1.0e6
+        big["layers.5.weight"][7, 9] = -2.0e5
+        mh = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=mode)
+        mh.load_state_dict(big)
+        mh = mh.cuda().eval()
+        with torch.no_grad():
+            a = mh(x)
+        mh.flat_params().ensure()
+        mh._gen += 1
+        with torch.no_grad():
+            b = mh(x)
+        assert torch.isfinite(a).all() and torch.equal(a, b), mode
     m, p = model_v1(N, "fog", "f16x3")
     out = m.train()(x[:64].cuda())
     out.sum().backward()

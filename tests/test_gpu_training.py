@@ -962,9 +962,9 @@ def test_train_cli_data_parallel_matches_one_process(N, tmp_path):
         s_.bind(("127.0.0.1", 0))
         port = s_.getsockname()[1]
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NERF_TRAIN_BACKEND="gloo", NERF_TRAIN_FORCE_DEVICE="0")
+    env = dict(os.environ)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           "-m", "nerf_few_shot_limitations_amd.train_cli"] + common + ["--out", str(tmp_path / "two"), "--data-parallel"]
+           "-m", "nerf_few_shot_limitations_amd.train_cli"] + common + ["--out", str(tmp_path / "two"), "--data-parallel", "--rehearse"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=repo, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     two = json.load(open(tmp_path / "two" / "train_log.json"))

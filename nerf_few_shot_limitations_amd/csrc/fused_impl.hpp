@@ -251,6 +251,20 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                     pt[0] = point_on_ray(SQ(n, F_OX), SQ(n, F_DX), zc);
                     pt[1] = point_on_ray(SQ(n, F_OY), SQ(n, F_DY), zc);
                     pt[2] = point_on_ray(SQ(n, F_OZ), SQ(n, F_DZ), zc);
+                    // V3, first pass: start the feature-map gather of this column BEFORE its positional encoding, blend behind it
+                    DinoTaps tp;
+                    DinoRaw<Net::kDino ? Net::KT0 - KT0 : 1> raw;
+                    bool split_gather = false;
+                    if constexpr (Net::kDino && PASS == 0) {
+#ifdef NRF_ABLATE_BUILD
+                        if (!(P.net.ablate & (32 | 256)))
+#endif
+                        {
+                            tp = dino_taps(a.dino, pt);
+                            raw.issue(a.dino.features, tp, h);
+                            split_gather = true;
+                        }
+                    }
                     Act e1[KT0];
 #ifdef NRF_ABLATE_BUILD
                     // timing experiments on V3 (results are wrong): 64 = the second fusion pass reuses un-gated first-layer tiles of the
@@ -276,7 +290,10 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
                             else { tp.off[0] = tp.off[1] = tp.off[2] = tp.off[3] = -1; held[n].gather(a.dino.features, tp, h); }
                         } else
 #endif
-                        if constexpr (PASS == 0) held[n].gather(a.dino.features, dino_taps(a.dino, pt), h);
+                        if constexpr (PASS == 0) {
+                            if (split_gather) held[n].finish(raw, tp);
+                            else held[n].gather(a.dino.features, dino_taps(a.dino, pt), h);      // (ablation 256: the round-2 order)
+                        }
                         Act dt[DT];
                         held[n].template tiles<PASS>(w1[n], dt);
 #pragma unroll
@@ -539,13 +556,19 @@ __global__ void __launch_bounds__(WAVES * 64) render_queue_kernel(const RenderKA
                 p[0] = point_on_ray(SQ(n, F_OX), SQ(n, F_DX), zc);
                 p[1] = point_on_ray(SQ(n, F_OY), SQ(n, F_DY), zc);
                 p[2] = point_on_ray(SQ(n, F_OZ), SQ(n, F_DZ), zc);
+                DinoTaps tp;
+                DinoRaw<Net::kDino ? Net::KT0 - KT0 : 1> raw;
+                if constexpr (Net::kDino && PASS == 0) {          // the gather starts before the encoding and is blended behind it (render_kernel)
+                    tp = dino_taps(a.dino, p);
+                    raw.issue(a.dino.features, tp, h);
+                }
                 Act e1[KT0];
                 encode3<Mode, LP>(p, h, e1, w0[n]);
 #pragma unroll
                 for (int t = 0; t < KT0; ++t) x[t][n] = e1[t];
                 if constexpr (Net::kDino) {
                     constexpr int DT = Net::KT0 - KT0;
-                    if constexpr (PASS == 0) held[n].gather(a.dino.features, dino_taps(a.dino, p), h);
+                    if constexpr (PASS == 0) held[n].finish(raw, tp);
                     Act dt[DT];
                     held[n].template tiles<PASS>(w1[n], dt);
 #pragma unroll

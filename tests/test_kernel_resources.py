@@ -34,13 +34,16 @@ def test_16bit_fused_kernels_use_no_scratch_and_park_operands_in_agprs(res, kern
     assert len(ks) >= 4                                          # V1, V2, V3 (64-d), V3 (128-d)
     for name, r in ks.items():
         if "NetV3" in name:
-            # V3 renderers: f16 (the headline mode) 1-5 spilled registers at either feature width (round 2: 17-33 / 71-87); bf16 holds its
+            # V3 renderers: f16 (the headline mode) 3-5 spilled registers at either feature width, 11-13 in the ray-queue kernel (round 2: 17-33 /
+            # 71-87); bf16 holds its
             # gathered channels in fp32 at every width -- a packed hold costs it 24 dB (nets.hpp:DinoHeld) -- and spills 50-53 registers at
             # dino_dim 128.  The staged forward: 18-20.  36 bytes of every private segment are a reservation no instruction touches.
             if "forward_kernel" in name:
                 lim = (20, 84)
             elif "ModeBF16" in name:
-                lim = (56, 240) if ", 12, 4>," in name else (12, 52)
+                lim = (60, 256) if ", 12, 4>," in name else (12, 52)
+            elif "render_queue_kernel" in name:
+                lim = (13, 88)
             else:
                 lim = (5, 56)
             assert r["vgpr_spill"] <= lim[0] and r["scratch"] <= lim[1], (name, r)

@@ -249,40 +249,42 @@ def main(argv=None):
         holding every frame, the exchange just no longer sits between two renders.  A buffer is rendered into again only after the
         gather that read it has completed (work.wait() orders the render stream behind it)."""
         jobs = [make_job(n_views) for _ in range(2 if (overlap and world > 1) else 1)]
-        pending = [None] * len(jobs)
         frames = [None] * len(jobs)
+        async_gather = world > 1 and backend == "nccl" and len(jobs) == 2
+        ex = tiles.OverlappedGather([job.buf for job in jobs]) if async_gather else None      # the double-buffered exchange (tiles.py)
         kev, gev = [], []
 
         def step(i, timed):
             k = i % len(jobs)
             job = jobs[k]
-            if pending[k] is not None:
-                pending[k].wait()                          # the previous gather out of this job's buffer
-                pending[k] = None
             if timed:
                 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-                e0.record()
-            job.launch()                                   # ONE render kernel launch: this rank's tiles of all views, written
-            if timed:                                      # straight into the gather buffer
-                e1.record()
-            if world > 1:
-                if backend != "nccl":
-                    frames[k] = tiles.gather_frames(job.buf.cpu(), H * W, tile_rays)
-                elif len(jobs) == 1:
-                    frames[k] = tiles.gather_frames(job.buf, H * W, tile_rays)          # ONE all_gather (RCCL) + the view into frame order
-                else:
-                    if frames[k] is None:
-                        frames[k] = torch.empty((world,) + tuple(job.buf.shape), dtype=job.buf.dtype, device=dev)
-                    pending[k] = dist.all_gather_into_tensor(frames[k].view(-1), job.buf.view(-1), async_op=True)
+            if async_gather:
+                def render(slot):
+                    if timed:
+                        e0.record()
+                    jobs[slot].launch()                    # ONE render kernel launch: this rank's tiles of all views, written
+                    if timed:                              # straight into the gather buffer
+                        e1.record()
+                ex.step(render)                            # waits for the gather that last read this buffer, renders, enqueues the all_gather
+            else:
+                if timed:
+                    e0.record()
+                job.launch()
+                if timed:
+                    e1.record()
+                if world > 1:
+                    if backend != "nccl":
+                        frames[k] = tiles.gather_frames(job.buf.cpu(), H * W, tile_rays)
+                    else:
+                        frames[k] = tiles.gather_frames(job.buf, H * W, tile_rays)          # ONE all_gather (RCCL) + the view into frame order
             if timed:
                 e2.record()
                 kev.append((e0, e1)); gev.append((e1, e2))
 
         def drain():
-            for k in range(len(jobs)):
-                if pending[k] is not None:
-                    pending[k].wait()
-                    pending[k] = None
+            if ex is not None:
+                ex.drain()
 
         for i in range(warmup):
             step(i, False)

@@ -144,6 +144,49 @@ class TileJob:
         return self.buf
 
 
+class OverlappedGather:
+    """The exchange of a render loop, double-buffered: the all_gather of step i runs (on the backend's own stream / thread) while
+    step i+1 renders into the OTHER buffer.  `bufs` are the per-slot local buffers the renders write (one: serial exchange, two:
+    overlapped); `step(render)` waits for the gather that last read the slot's buffer, calls `render(slot)` -- which must write
+    `bufs[slot]` -- and enqueues the asynchronous all_gather of that buffer.  A buffer is therefore never rewritten before the
+    collective that reads it has completed, and `gathered(slot)` is valid once `wait(slot)` / `drain()` returned.  Every rank ends
+    every step holding every rank's rows: (world,) + buf.shape.  Used by bench.py over RCCL; tests/test_tiles_gloo.py drives the
+    same object over gloo on CPU tensors with two ranks and checks every step's rows."""
+
+    def __init__(self, bufs, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.collective = dist.is_initialized()            # a one-rank world still goes through the backend (tests/rccl_worker.py: RCCL)
+        self.world = dist.get_world_size(group) if self.collective else 1
+        self.bufs = list(bufs)
+        self.out = [torch.empty((self.world,) + tuple(b.shape), dtype=b.dtype, device=b.device) for b in self.bufs]
+        self.pending = [None] * len(self.bufs)
+        self.i = 0
+
+    def wait(self, slot):
+        if self.pending[slot] is not None:
+            self.pending[slot].wait()
+            self.pending[slot] = None
+
+    def step(self, render):
+        slot = self.i % len(self.bufs)
+        self.wait(slot)                                    # the previous gather out of this slot's buffer
+        render(slot)
+        if self.collective:
+            self.pending[slot] = self.dist.all_gather_into_tensor(self.out[slot].view(-1), self.bufs[slot].view(-1), group=self.group, async_op=True)
+        else:
+            self.out[slot][0].copy_(self.bufs[slot])
+        self.i += 1
+        return slot
+
+    def drain(self):
+        for slot in range(len(self.bufs)):
+            self.wait(slot)
+
+    def gathered(self, slot):
+        return self.out[slot]
+
+
 def render_tiles(model, H, W, focal, c2w, near, far, N_samples, rank, world, tile_rays, **kw):
     """This rank's tiles of a batch of V views (c2w (V,4,4), or one (4,4) pose) -> (V, per_rank*tile_rays, 4) = [r,g,b,depth].
     Up to 8 views go into one kernel launch."""

@@ -1,7 +1,7 @@
 """Worker of tests/test_gpu_parity.py::test_rccl_backend_single_rank: the bench's gather sequence on the REAL collective backend
 ("nccl" = RCCL) with a world of one rank -- two ranks cannot share the test box's one GPU under RCCL ("Duplicate GPU detected"),
-but a one-rank world still goes through RCCL's communicator setup, the asynchronous all_gather_into_tensor on RCCL's stream,
-work.wait() and the barrier / all_reduce calls bench.py makes.  Prints 'rccl ok' when every step's frame equals render_camera."""
+but a one-rank world still goes through RCCL's communicator setup, the asynchronous all_gather_into_tensor on RCCL's stream
+(tiles.OverlappedGather: the object bench.py's N > 1 loop uses), work.wait() and the barrier / all_reduce calls bench.py makes.  Prints 'rccl ok' when every step's frame equals render_camera."""
 import os
 import sys
 
@@ -30,17 +30,15 @@ def main():
     ref_rgb, ref_depth = N.render_camera(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S)
     tile_rays = 4 * W
     jobs = [tiles.TileJob(m, H, W, O.focal_for(W), c2w, 2.0, 6.0, S, rank, world, tile_rays, device=dev) for _ in range(2)]
-    frames = [torch.empty((world,) + tuple(j.buf.shape), device=dev) for j in jobs]
-    pending = [None, None]
-    for i in range(6):                                                        # bench.py's overlapped sequence
-        k = i % 2
-        if pending[k] is not None:
-            pending[k].wait()
-        jobs[k].buf.zero_()
-        jobs[k].launch()
-        pending[k] = dist.all_gather_into_tensor(frames[k].view(-1), jobs[k].buf.view(-1), async_op=True)
-    for k in range(2):
-        pending[k].wait()
+    ex = tiles.OverlappedGather([j.buf for j in jobs])                        # bench.py's overlapped exchange, the very object
+
+    def render(slot):
+        jobs[slot].buf.zero_()
+        jobs[slot].launch()
+    for i in range(6):
+        ex.step(render)
+    ex.drain()
+    frames = [ex.gathered(k) for k in range(2)]
     torch.cuda.synchronize()
     dist.barrier()
     t = torch.tensor([1.5], dtype=torch.float64, device=dev)

@@ -97,3 +97,60 @@ def test_flat_gradient_all_reduce_gloo(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(r, True) for r in range(world)]
+
+
+def _overlap_worker(rank, world, port, n_bufs, steps, q):
+    """bench.py's render / exchange loop on CPU tensors with REAL asynchronous collectives: every step's render writes
+    (rank, step, element index) into its slot's buffer; after the loop (and, for the slot about to be reused, during it) every rank
+    must hold exactly that pattern from every rank -- a buffer rewritten before its gather finished, or a gather read before it
+    landed, shows up as a wrong step number."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 4096
+        bufs = [torch.zeros(3, n, 4) for _ in range(n_bufs)]
+        ex = tiles.OverlappedGather(bufs)
+        ok = True
+        last_step_of_slot = {}
+
+        def check(slot, step):
+            g = ex.gathered(slot)
+            good = g.shape == (world, 3, n, 4)
+            for r in range(world):
+                good = good and bool((g[r, :, :, 0] == r).all()) and bool((g[r, :, :, 1] == step).all())
+                good = good and torch.equal(g[r, 0, :, 2], torch.arange(n, dtype=torch.float32))
+            return good
+
+        for step in range(steps):
+            def render(slot, step=step):
+                if slot in last_step_of_slot:                  # the gather that read this buffer has been waited for: its result is final
+                    nonlocal ok
+                    ok = ok and check(slot, last_step_of_slot[slot])
+                b = bufs[slot]
+                b[..., 0] = rank
+                b[..., 1] = step
+                b[..., 2] = torch.arange(n, dtype=torch.float32)
+            slot = ex.step(render)
+            last_step_of_slot[slot] = step
+        ex.drain()
+        for slot, step in last_step_of_slot.items():
+            ok = ok and check(slot, step)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_bufs", [(2, 2), (2, 1), (3, 2)])
+def test_overlapped_gather_protocol_gloo(world, n_bufs):
+    """tiles.OverlappedGather (the double-buffered exchange of bench.py's N > 1 loop) with async all_gathers over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, n_bufs, 7, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(world)]

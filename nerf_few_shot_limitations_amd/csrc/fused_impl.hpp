@@ -2,7 +2,7 @@
 // forward, hand-written for gfx950 (CDNA4).  See mlp_core.hpp for the MFMA / weight-stream design.
 //
 // Work mapping of the renderer: a persistent workgroup (4 waves, one per SIMD: 64 sample columns each in the 16-bit modes, 32 in
-// the fp32 / split-f16 modes -- "Workgroup geometry" below; 1 workgroup per CU because of its ~147 KiB of LDS) walks ray tiles.
+// the fp32 / split-f16 modes -- "Workgroup geometry" below; 1 workgroup per CU because of its 142 KiB of LDS) walks ray tiles.
 // Inside a wave LANE <-> RAY: the wave marches its rays front to back, so a ray's transmittance / colour / depth accumulators
 // belong to ONE lane (parked in LDS between passes) and compositing never crosses lanes.  Early ray termination (ert_eps > 0)
 // runs on render_queue_kernel: columns refill from a ray queue.
@@ -16,8 +16,8 @@
 namespace nrf {
 
 constexpr int kBiasMaxFloats = 4096;                                   // 16 KiB bias table
-constexpr int kLdsRing = kSlots * kChunkBytes;                         // 128 KiB
-constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64 + 4096;   // staged forward: ring + bias table (+ the renderers' vote flags and depth-ladder cache)
+constexpr int kLdsRing = kSlots * kChunkBytes;                         // 96 KiB (6 slots of 16 KiB)
+constexpr int kLdsBytes = kLdsRing + kBiasMaxFloats * 4 + 64 + 4096;   // staged forward / training chain kernels: ring + bias table (+ slack)
 constexpr int kLadderLds = 4096;                                        // the renderers keep the whole depth ladder in LDS (n_samples <= 4096: api.cpp:check_opts)
 constexpr int kRenderThreads = 256;                                     // both renderers run 4 waves
 constexpr int kLdsBytesQueue = kLdsRing + kBiasMaxFloats * 4 + 64 + kLadderLds * 4 + 14 * kRenderThreads * 4;   // + 14 floats of per-lane ray state

@@ -161,3 +161,57 @@ def test_differentiable_route_takes_empty_and_single_sample_batches(N):
     assert torch.isfinite(r["rgb"]).all()
     r["rgb"].sum().backward()
     assert all(q.grad is not None and torch.isfinite(q.grad).all() for q in model.parameters())
+
+
+# ---------------------------------------------------------------------------------------------
+# the autograd node behind render_rays against loss.backward() of the REFERENCE's own modules
+# (tests/golden/train_grads.npz, captured by tests/golden/make_golden.py:training() in the build container)
+# ---------------------------------------------------------------------------------------------
+def _thin(t):
+    return t[::4] if t.ndim == 2 and t.numel() > 20000 else t
+
+
+@pytest.mark.parametrize("net", ["v1", "v2", "v3"])
+def test_render_node_matches_reference_gradients(N, golden, net):
+    """`training._RenderFn` (saving forward -> composite | composite backward -> dZ chain + weight gradients as ONE autograd node)
+    fed the golden inputs: loss and every parameter gradient of the reference's modules -- nerf_model.NeRFMLP + volume_render_radiance,
+    DensityMLP + ColorMLP + VolumeRenderer + NeRFLoss's weights regulariser, NeRFWithDINO + VolumeRenderer -- within 2e-4 of each
+    tensor's max (fp32 mode)."""
+    from nerf_few_shot_limitations_amd.training import _RenderFn
+    g = golden("train_grads")
+    R, S = g[f"{net}_z"].shape
+    z = torch.from_numpy(g[f"{net}_z"]).cuda()
+    rd = torch.from_numpy(g[f"{net}_rays_d"]).cuda()
+    tgt = torch.from_numpy(g[f"{net}_target"]).cuda()
+    pts = torch.from_numpy(g[f"{net}_pts"]).reshape(-1, 3).cuda()
+    if net == "v1":
+        m = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=3, mma_mode="f32")
+        m.load_state_dict(O.make_weights("v1", 0, "solid", n_layers=3))
+        x, dirs, dino = N.PositionalEncoding(10)(pts), None, None
+    else:
+        dirs = torch.from_numpy(g[f"{net}_dirs"]).reshape(-1, 3).cuda().contiguous()
+        if net == "v2":
+            m = N.NeRFMLP(pos_freq=10, dir_freq=4, hidden_dim=256, num_density_layers=3, use_dino=False, mma_mode="f32")
+            m.load_state_dict(O.make_weights("v2", 1, "solid", n_layers=3), strict=False)
+            dino = None
+        else:
+            m = N.NeRFMLP(pos_freq=12, dir_freq=4, hidden_dim=256, num_density_layers=3, use_dino=True, dino_dim=64, mma_mode="f32")
+            m.load_state_dict(O.make_weights("v3", 2, "solid", n_layers=3, dino_dim=64), strict=False)
+            dino = torch.from_numpy(g["v3_dino"]).reshape(-1, 64).cuda().contiguous()
+        x = pts
+    m = m.cuda().train()
+    rgb_map, depth, w = _RenderFn.apply(m, x.contiguous(), dirs, dino, z, rd, 0, None, *m.flat_params().params())
+    loss = torch.nn.functional.mse_loss(rgb_map, tgt)
+    if net == "v2":
+        loss = loss + 0.01 * torch.mean(w ** 2)                    # nerf_mlp.py:236-252 (NeRFLoss's regulariser, as the golden was captured)
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{net}_loss"])) < 1e-5 * float(g[f"{net}_loss"]) + 1e-7
+    assert np.abs(rgb_map.detach().cpu().numpy() - g[f"{net}_pred"]).max() < 1e-4
+    checked = 0
+    for name, q in m.named_parameters():
+        key = f"{net}_grad_{name}"
+        if key in g:
+            ref = g[key]
+            assert np.abs(_thin(q.grad).cpu().numpy() - ref).max() <= 2e-4 * np.abs(ref).max(), name
+            checked += 1
+    assert checked >= 10

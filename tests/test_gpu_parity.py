@@ -968,6 +968,70 @@ def test_maximum_sample_count_and_in_kernel_ladders(N, pmode):
             assert maxdiff(rgb, ref["rgb"]) <= TOL and maxdiff(depth, ref["depth"]) <= TOL, (lindisp, S2, eps)
 
 
+def test_randomized_render_configurations_match_the_oracle(N):
+    """A seeded sweep over what a caller can combine: family (V1 / V2 / V3), parity-grade mode, ray count (ragged tiles), sample count
+    (2 ... 97: every samples-per-pass split the launcher may pick, sample counts that divide nothing), jitter, disparity spacing, white
+    background, early termination with a vanishing threshold (the ray-queue kernel), explicit rays vs the in-kernel camera.  rgb / depth /
+    weights / depths against the oracle at the 1e-4 bar."""
+    rng = np.random.RandomState(20260305)
+    c2w = T(O.LEGO_LIKE_C2W)
+    models = {}
+    for it in range(28):
+        variant = ("v1", "v2", "v3")[rng.randint(3)]
+        pmode = PARITY[rng.randint(len(PARITY))]
+        Hh, Ww = int(rng.randint(1, 29)), int(rng.randint(1, 29))
+        S = int(rng.choice([2, 3, 5, 8, 16, 31, 32, 33, 48, 64, 97]))
+        perturb, lindisp, white = bool(rng.randint(2)), bool(rng.randint(2)), bool(rng.randint(2))
+        queue = bool(rng.randint(4) == 0)
+        if (variant, pmode) not in models:
+            models[(variant, pmode)] = {"v1": model_v1, "v2": model_v2, "v3": model_v3}[variant](N, "solid", pmode)
+        m, p = models[(variant, pmode)]
+        ro, rd = O.get_rays(Hh, Ww, O.focal_for(max(Ww, 2)), c2w)
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        Rr = ro.shape[0]
+        tr = torch.from_numpy(rng.rand(Rr, S).astype(np.float32)) if perturb else None
+        dino = dict(features=dino_map(), pose=c2w, focal=O.focal_for(max(Ww, 2)), H=Hh, W=Ww) if variant == "v3" else None
+        tag = (it, variant, pmode, Hh, Ww, S, perturb, lindisp, white, queue)
+        out = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=tr, lindisp=lindisp, white_bkgd=white, ert_eps=1e-30 if queue else 0.0,
+                            dino=dino, return_z=True)
+        # the oracle on the kernel's own depths: with disparity spacing the ladder's last ulp is host dependent and the encoding amplifies it
+        assert maxdiff(out["z_vals"], O.sample_points_along_rays(ro, rd, 2.0, 6.0, S, tr, lindisp)[1]) <= 2e-6, tag
+        ref = O.render_rays(p, variant, ro, rd, 2.0, 6.0, S, white_bkgd=white, dino=dino, z_in=out["z_vals"].cpu())
+        assert maxdiff(out["rgb"], ref["rgb"]) <= TOL and maxdiff(out["depth"], ref["depth"]) <= TOL, tag
+        assert maxdiff(out["weights"], ref["weights"]) <= TOL, tag
+        if not perturb and not queue and variant != "v3":       # the camera entry point generates the same rays in-kernel: same bits
+            cam = N.render_camera(m, Hh, Ww, O.focal_for(max(Ww, 2)), c2w, 2.0, 6.0, S, lindisp=lindisp, white_bkgd=white)
+            assert torch.equal(cam[0], out["rgb"]) and torch.equal(cam[1], out["depth"]), tag
+
+
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+def test_randomized_launch_cuts_never_change_a_bit(N, mode):
+    """The throughput modes carry no 1e-4 claim, but the same invariance as the parity-grade ones: a ray's result depends on nothing
+    but the ray -- not on how many rays share its launch (which picks the samples-per-pass split, the tile it lands in, the lane that
+    owns it).  Seeded sweep: a launch vs the same rays cut at a random place, plain and ray-queue kernels, V1 / V2 / V3, with jitter."""
+    rng = np.random.RandomState(7 if mode == "f16" else 11)
+    c2w = T(O.LEGO_LIKE_C2W)
+    models = {v: {"v1": model_v1, "v2": model_v2, "v3": model_v3}[v](N, "solid", mode)[0] for v in ("v1", "v2", "v3")}
+    for it in range(18):
+        variant = ("v1", "v2", "v3")[it % 3]
+        m = models[variant]
+        Hh, Ww = int(rng.randint(2, 60)), int(rng.randint(2, 60))
+        S = int(rng.choice([3, 8, 21, 32, 48, 64]))
+        eps = 1e-30 if rng.randint(3) == 0 else 0.0
+        ro, rd = N.get_rays(Hh, Ww, O.focal_for(Ww), c2w)
+        ro, rd = ro.reshape(-1, 3), rd.reshape(-1, 3)
+        Rr = ro.shape[0]
+        tr = torch.from_numpy(rng.rand(Rr, S).astype(np.float32)).cuda()
+        dino = dict(features=dino_map(), pose=c2w, focal=O.focal_for(Ww), H=Hh, W=Ww) if variant == "v3" else None
+        cut = int(rng.randint(1, Rr))
+        whole = N.render_rays(m, ro, rd, 2.0, 6.0, S, t_rand=tr, ert_eps=eps, dino=dino, return_z=True)
+        a = N.render_rays(m, ro[:cut], rd[:cut], 2.0, 6.0, S, t_rand=tr[:cut], ert_eps=eps, dino=dino, return_z=True)
+        b = N.render_rays(m, ro[cut:], rd[cut:], 2.0, 6.0, S, t_rand=tr[cut:], ert_eps=eps, dino=dino, return_z=True)
+        for k in ("rgb", "depth", "weights", "z_vals"):
+            assert torch.equal(whole[k], torch.cat([a[k], b[k]])), (it, variant, mode, Hh, Ww, S, eps, cut, k)
+        assert torch.isfinite(whole["rgb"]).all() and float(whole["weights"].sum(-1).max()) <= 1 + 1e-4
+
+
 # ------------------------------------------------------------------ a3 hierarchical resampling (parity UNPINNED: vs our oracle only)
 def test_sample_pdf_vs_oracle(N):
     R, S, Ni = 333, 64, 32

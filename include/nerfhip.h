@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRF_ABI_VERSION 4
+#define NRF_ABI_VERSION 5
 
 /* error codes */
 #define NRF_OK            0
@@ -290,6 +290,20 @@ int nrf_composite_backward(const float* rgb, int rgb_stride, const float* sigma,
 /* `rgb_weight * nn.MSELoss()(pred, target)` (train.py:36-44) and its gradient in one launch: loss[0] = weight * mean((pred -
  * target)^2) over n values, g_pred = d loss / d pred.  n <= 2^22 (ray batches). */
 int nrf_mse_grad(const float* pred, const float* target, int64_t n, float weight, float* g_pred, float* loss, void* stream);
+
+/* nrf_composite + nrf_mse_grad + nrf_composite_backward in ONE launch (the three steps between the network's forward and its
+ * backward in the reference's train_step, train.py:236,36-44,285): a ray's loss gradient needs only its own prediction and
+ * target.  d_rgb / d_sigma are bit-equal to the three-call sequence; pred (n_rays,3) may be NULL.
+ *   ray_loss : n_rays floats of scratch (the rays' squared errors);
+ *   loss     : receives weight * mean((pred - target)^2) over 3 n_rays values, summed in a fixed order;
+ *   ticket   : one 32-bit counter of device memory that must be ZERO before the first launch and is left zero by every launch
+ *              (launches sharing a ticket must be ordered on one stream);
+ *   zero_buf : optional, zero_n floats cleared by the same launch (the flat gradient vector nrf_mlp_backward* adds into). */
+int nrf_composite_mse_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride,
+                               const float* z_vals, const float* rays_d, int64_t n_rays, int n_samples, int white_bkgd,
+                               const float* target, float weight, float* pred,
+                               float* d_rgb, int d_rgb_stride, float* d_sigma, int d_sigma_stride,
+                               float* ray_loss, float* loss, uint32_t* ticket, float* zero_buf, int64_t zero_n, void* stream);
 
 /* torch.optim.Adam's update (train.py:113-118; no amsgrad) on flat vectors;
  * step counts from 1. */

@@ -92,6 +92,9 @@ SIGNATURES = {
     "nrf_composite_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "nrf_mse_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "nrf_composite_mse_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                             C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "nrf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_void_p]),
 }
@@ -114,7 +117,7 @@ def lib() -> C.CDLL:
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(handle, name)          # AttributeError if the symbol is not exported
                 fn.restype, fn.argtypes = res, args
-            if handle.nrf_abi_version() != 4:
+            if handle.nrf_abi_version() != 5:
                 raise RuntimeError("libnerfhip.so ABI version mismatch")
             for which, st in enumerate((nrf_arch, nrf_linear, nrf_dino, nrf_render_opts)):
                 if handle.nrf_abi_sizeof(which) != C.sizeof(st):

@@ -602,6 +602,20 @@ int nrf_mse_grad(const float* pred, const float* target, int64_t n, float weight
     return r == NRF_OK ? NRF_OK : fail(r, "mse launch failed");
 }
 
+int nrf_composite_mse_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z_vals, const float* rays_d,
+                               int64_t n_rays, int n_samples, int white_bkgd, const float* target, float weight, float* pred, float* d_rgb,
+                               int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* loss, uint32_t* ticket, float* zero_buf,
+                               int64_t zero_n, void* stream) {
+    if (n_rays <= 0 || n_rays > ((int64_t)1 << 30) || n_samples < 1 || n_samples > 4096) return fail(NRF_EINVAL, "nrf_composite_mse_backward: bad sizes");
+    if (rgb_stride < 3 || sigma_stride < 1 || d_rgb_stride < 3 || d_sigma_stride < 1) return fail(NRF_EINVAL, "bad strides");
+    if (!rgb || !sigma || !z_vals || !rays_d || !target || !d_rgb || !d_sigma || !ray_loss || !loss || !ticket) return fail(NRF_EINVAL, "null pointer");
+    if (zero_n < 0 || (zero_n > 0 && !zero_buf)) return fail(NRF_EINVAL, "zero_buf is NULL");
+    const int r = nrf::launch_composite_mse_backward(rgb, rgb_stride, sigma, sigma_stride, z_vals, rays_d, n_rays, n_samples, white_bkgd, target,
+                                                     weight, pred, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, ray_loss, loss, ticket, zero_buf, zero_n,
+                                                     (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "composite + mse + backward launch failed");
+}
+
 int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, void* stream) {
     if (n < 0 || step < 1) return fail(NRF_EINVAL, "bad n / step");

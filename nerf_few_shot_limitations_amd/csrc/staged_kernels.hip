@@ -4,6 +4,8 @@
 // stage-wise parity tests.  All of them are HBM-bound elementwise / per-ray kernels: the
 // layouts are the reference's own row-major tensors, reads and writes are coalesced along the
 // innermost axis wherever the reference layout allows it.
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace nrf {
@@ -96,6 +98,46 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// One ray on one wave (LANE <-> sample, 64-sample segments front to back): every lane returns the ray's sums
+struct RaySums { float r, g, b, depth, acc; };
+__device__ __forceinline__ RaySums composite_ray(const float* __restrict__ rgb, int rgb_stride, const float* __restrict__ sigma, int sigma_stride,
+                                                 const float* __restrict__ z, const float* __restrict__ rays_d, int64_t r, int S, int lane,
+                                                 float* __restrict__ out_w) {
+    const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+    const float norm = ray_norm(d);
+    float T_in = 1.0f;                                   // transmittance entering this 64-sample segment
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f, sd = 0.0f, sa = 0.0f;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int s = s0 + lane;
+        const bool valid = s < S;
+        const int64_t i = r * S + (valid ? s : S - 1);
+        const float zc = z[i];
+        float zn = __shfl_down(zc, 1, 64);
+        if (lane == 63 && s + 1 < S) zn = z[i + 1];
+        const bool last = (s + 1 == S);
+        const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
+        float alpha = 0.0f;
+        if (valid) alpha = __fsub_rn(1.0f, expf(__fmul_rn(-fmaxf(sigma[i * sigma_stride], 0.0f), dist)));
+        const float f = valid ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+        const float incl = wave_incl_prod(f, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float w = __fmul_rn(alpha, __fmul_rn(T_in, excl));
+        if (valid) {
+            if (out_w) out_w[i] = w;
+            sr = __fadd_rn(sr, __fmul_rn(w, rgb[i * rgb_stride]));
+            sg = __fadd_rn(sg, __fmul_rn(w, rgb[i * rgb_stride + 1]));
+            sb = __fadd_rn(sb, __fmul_rn(w, rgb[i * rgb_stride + 2]));
+            sd = __fadd_rn(sd, __fmul_rn(w, zc));
+            sa = __fadd_rn(sa, w);
+        }
+        T_in = __fmul_rn(T_in, __shfl(incl, 63, 64));
+    }
+    RaySums o;
+    o.r = wave_sum(sr); o.g = wave_sum(sg); o.b = wave_sum(sb); o.depth = wave_sum(sd); o.acc = wave_sum(sa);
+    return o;
+}
+
 __global__ void __launch_bounds__(kBlock) composite_kernel(const float* __restrict__ rgb, int rgb_stride, const float* __restrict__ sigma,
                                                            int sigma_stride, const float* __restrict__ z, const float* __restrict__ rays_d,
                                                            int64_t n_rays, int S, int white_bkgd, float* __restrict__ out_rgb,
@@ -104,44 +146,14 @@ __global__ void __launch_bounds__(kBlock) composite_kernel(const float* __restri
     const int64_t wave0 = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
     for (int64_t r = wave0; r < n_rays; r += n_waves) {
-        const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
-        const float norm = ray_norm(d);
-        float T_in = 1.0f;                                   // transmittance entering this 64-sample segment
-        float sr = 0.0f, sg = 0.0f, sb = 0.0f, sd = 0.0f, sa = 0.0f;
-        for (int s0 = 0; s0 < S; s0 += 64) {
-            const int s = s0 + lane;
-            const bool valid = s < S;
-            const int64_t i = r * S + (valid ? s : S - 1);
-            const float zc = z[i];
-            float zn = __shfl_down(zc, 1, 64);
-            if (lane == 63 && s + 1 < S) zn = z[i + 1];
-            const bool last = (s + 1 == S);
-            const float dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
-            float alpha = 0.0f;
-            if (valid) alpha = __fsub_rn(1.0f, expf(__fmul_rn(-fmaxf(sigma[i * sigma_stride], 0.0f), dist)));
-            const float f = valid ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
-            const float incl = wave_incl_prod(f, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
-            const float w = __fmul_rn(alpha, __fmul_rn(T_in, excl));
-            if (valid) {
-                if (out_w) out_w[i] = w;
-                sr = __fadd_rn(sr, __fmul_rn(w, rgb[i * rgb_stride]));
-                sg = __fadd_rn(sg, __fmul_rn(w, rgb[i * rgb_stride + 1]));
-                sb = __fadd_rn(sb, __fmul_rn(w, rgb[i * rgb_stride + 2]));
-                sd = __fadd_rn(sd, __fmul_rn(w, zc));
-                sa = __fadd_rn(sa, w);
-            }
-            T_in = __fmul_rn(T_in, __shfl(incl, 63, 64));
-        }
-        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb); sd = wave_sum(sd); sa = wave_sum(sa);
+        RaySums o = composite_ray(rgb, rgb_stride, sigma, sigma_stride, z, rays_d, r, S, lane, out_w);
         if (lane == 0) {
             if (white_bkgd) {
-                const float bg = __fsub_rn(1.0f, sa);
-                sr = __fadd_rn(sr, bg); sg = __fadd_rn(sg, bg); sb = __fadd_rn(sb, bg);
+                const float bg = __fsub_rn(1.0f, o.acc);
+                o.r = __fadd_rn(o.r, bg); o.g = __fadd_rn(o.g, bg); o.b = __fadd_rn(o.b, bg);
             }
-            out_rgb[r * 3] = sr; out_rgb[r * 3 + 1] = sg; out_rgb[r * 3 + 2] = sb;
-            if (out_depth) out_depth[r] = sd;
+            out_rgb[r * 3] = o.r; out_rgb[r * 3 + 1] = o.g; out_rgb[r * 3 + 2] = o.b;
+            if (out_depth) out_depth[r] = o.depth;
         }
     }
 }
@@ -164,6 +176,72 @@ __device__ __forceinline__ float wave_incl_sum_rev(float v, int lane) {
 
 constexpr int kMaxSegments = 64;     // S <= 4096
 
+// One ray on one wave; gr, gg, gb, gd = dL/d rgb_map, dL/d depth of the ray (wave-uniform), g_w = dL/d weights or NULL;
+// seg_T = the wave's LDS row of kMaxSegments floats
+__device__ __forceinline__ void composite_backward_ray(const float* __restrict__ rgb, int rgb_stride, const float* __restrict__ sigma,
+                                                       int sigma_stride, const float* __restrict__ z, const float* __restrict__ rays_d,
+                                                       int64_t r, int S, int lane, int white_bkgd, float gr, float gg, float gb, float gd,
+                                                       const float* __restrict__ g_w, float* __restrict__ d_rgb, int d_rgb_stride,
+                                                       float* __restrict__ d_sigma, int d_sigma_stride, float* seg_T) {
+    const int n_seg = (S + 63) / 64;
+    const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+    const float norm = ray_norm(d);
+    const float bg = white_bkgd ? __fadd_rn(__fadd_rn(gr, gg), gb) : 0.0f;
+    auto sample = [&](int s0, float& alpha, float& e, float& dist, float& f, float& zc, bool& valid, int64_t& i) {
+        const int s = s0 + lane;
+        valid = s < S;
+        i = r * S + (valid ? s : S - 1);
+        zc = z[i];
+        float zn = __shfl_down(zc, 1, 64);
+        if (lane == 63 && s + 1 < S) zn = z[i + 1];
+        const bool last = (s + 1 == S);
+        dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
+        e = valid ? expf(__fmul_rn(-fmaxf(sigma[i * sigma_stride], 0.0f), dist)) : 1.0f;
+        alpha = valid ? __fsub_rn(1.0f, e) : 0.0f;
+        f = valid ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
+    };
+    // pass 1, front to back: transmittance entering every 64-sample segment
+    float T_in = 1.0f;
+    for (int k = 0; k < n_seg; ++k) {
+        float alpha, e, dist, f, zc; bool valid; int64_t i;
+        sample(64 * k, alpha, e, dist, f, zc, valid, i);
+        if (lane == 0) seg_T[k] = T_in;
+        const float incl = wave_incl_prod(f, lane);
+        T_in = __fmul_rn(T_in, __shfl(incl, 63, 64));
+    }
+    // pass 2, back to front
+    float carry = 0.0f;                                  // sum of w_j v_j over all later segments
+    for (int k = n_seg - 1; k >= 0; --k) {
+        float alpha, e, dist, f, zc; bool valid; int64_t i;
+        sample(64 * k, alpha, e, dist, f, zc, valid, i);
+        const float incl = wave_incl_prod(f, lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = __fmul_rn(seg_T[k], excl);
+        const float w = __fmul_rn(alpha, T);
+        float v = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        if (valid) {
+            cr = rgb[i * rgb_stride]; cg = rgb[i * rgb_stride + 1]; cb = rgb[i * rgb_stride + 2];
+            v = __fadd_rn(__fadd_rn(__fmul_rn(gr, cr), __fmul_rn(gg, cg)), __fmul_rn(gb, cb));
+            v = __fadd_rn(v, __fmul_rn(gd, zc));
+            if (g_w) v = __fadd_rn(v, g_w[i]);
+            v = __fsub_rn(v, bg);
+        }
+        const float wv_ = valid ? __fmul_rn(w, v) : 0.0f;
+        const float incl_rev = wave_incl_sum_rev(wv_, lane);
+        const float suffix = __fadd_rn(__fsub_rn(incl_rev, wv_), carry);     // strictly later samples
+        carry = __fadd_rn(carry, __shfl(incl_rev, 0, 64));
+        if (valid) {
+            const float d_alpha = __fsub_rn(__fmul_rn(T, v), suffix / f);
+            const float sg = sigma[i * sigma_stride];
+            d_sigma[i * d_sigma_stride] = sg > 0.0f ? __fmul_rn(__fmul_rn(d_alpha, dist), e) : 0.0f;
+            d_rgb[i * d_rgb_stride] = __fmul_rn(w, gr);
+            d_rgb[i * d_rgb_stride + 1] = __fmul_rn(w, gg);
+            d_rgb[i * d_rgb_stride + 2] = __fmul_rn(w, gb);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(kBlock) composite_backward_kernel(const float* __restrict__ rgb, int rgb_stride, const float* __restrict__ sigma,
                                                                     int sigma_stride, const float* __restrict__ z,
                                                                     const float* __restrict__ rays_d, int64_t n_rays, int S, int white_bkgd,
@@ -174,66 +252,69 @@ __global__ void __launch_bounds__(kBlock) composite_backward_kernel(const float*
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t wave0 = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6;
     const int64_t n_waves = ((int64_t)gridDim.x * kBlock) >> 6;
-    const int n_seg = (S + 63) / 64;
     for (int64_t r = wave0; r < n_rays; r += n_waves) {
-        const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
-        const float norm = ray_norm(d);
         const float gr = g_rgb ? g_rgb[r * 3] : 0.0f, gg = g_rgb ? g_rgb[r * 3 + 1] : 0.0f, gb = g_rgb ? g_rgb[r * 3 + 2] : 0.0f;
         const float gd = g_depth ? g_depth[r] : 0.0f;
-        const float bg = white_bkgd ? __fadd_rn(__fadd_rn(gr, gg), gb) : 0.0f;
-        auto sample = [&](int s0, float& alpha, float& e, float& dist, float& f, float& zc, bool& valid, int64_t& i) {
-            const int s = s0 + lane;
-            valid = s < S;
-            i = r * S + (valid ? s : S - 1);
-            zc = z[i];
-            float zn = __shfl_down(zc, 1, 64);
-            if (lane == 63 && s + 1 < S) zn = z[i + 1];
-            const bool last = (s + 1 == S);
-            dist = last ? __fmul_rn(1e10f, norm) : __fmul_rn(__fsub_rn(zn, zc), norm);
-            e = valid ? expf(__fmul_rn(-fmaxf(sigma[i * sigma_stride], 0.0f), dist)) : 1.0f;
-            alpha = valid ? __fsub_rn(1.0f, e) : 0.0f;
-            f = valid ? __fadd_rn(__fsub_rn(1.0f, alpha), 1e-10f) : 1.0f;
-        };
-        // pass 1, front to back: transmittance entering every 64-sample segment
-        float T_in = 1.0f;
-        for (int k = 0; k < n_seg; ++k) {
-            float alpha, e, dist, f, zc; bool valid; int64_t i;
-            sample(64 * k, alpha, e, dist, f, zc, valid, i);
-            if (lane == 0) seg_T[wv][k] = T_in;
-            const float incl = wave_incl_prod(f, lane);
-            T_in = __fmul_rn(T_in, __shfl(incl, 63, 64));
+        composite_backward_ray(rgb, rgb_stride, sigma, sigma_stride, z, rays_d, r, S, lane, white_bkgd, gr, gg, gb, gd, g_w, d_rgb, d_rgb_stride,
+                               d_sigma, d_sigma_stride, seg_T[wv]);
+    }
+}
+
+// The three launches between the network's forward and its backward in a FusedStep -- compositor, `rgb_weight * nn.MSELoss()` with
+// its gradient, compositor backward (train.py:236,36-44,285) -- as ONE: the loss gradient of a ray needs nothing but the ray's own
+// prediction and target, d loss / d pred = 2 w (pred - target) / (3 R).  Same per-ray arithmetic as the three kernels (the two bodies
+// above), so d_rgb / d_sigma are bit-equal to the staged sequence.  The loss VALUE is summed in a fixed order (per-ray squared errors
+// in `ray_loss`, added by the last workgroup to finish: thread t takes rays t, t + 256, ..., then one butterfly and four partial
+// sums) -- reproducible run to run, not bit-equal to mse_grad_kernel's order.  Side job: `zero_buf` (the caller's flat gradient
+// vector, which the weight-gradient reduction adds into) is cleared by the same launch.
+__global__ void __launch_bounds__(kBlock) composite_mse_backward_kernel(const float* __restrict__ rgb, int rgb_stride,
+                                                                        const float* __restrict__ sigma, int sigma_stride,
+                                                                        const float* __restrict__ z, const float* __restrict__ rays_d,
+                                                                        int64_t n_rays, int S, int white_bkgd, const float* __restrict__ target,
+                                                                        float weight, float* __restrict__ pred, float* __restrict__ d_rgb,
+                                                                        int d_rgb_stride, float* __restrict__ d_sigma, int d_sigma_stride,
+                                                                        float* __restrict__ ray_loss, float* __restrict__ loss, unsigned* __restrict__ ticket,
+                                                                        float* __restrict__ zero_buf, int64_t zero_n) {
+    __shared__ float seg_T[kBlock / 64][kMaxSegments];
+    __shared__ float part[kBlock / 64];
+    __shared__ unsigned ticket_s;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t gtid = blockIdx.x * (int64_t)kBlock + threadIdx.x, n_threads = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = gtid; i < zero_n; i += n_threads) zero_buf[i] = 0.0f;
+    const float count = 3.0f * (float)n_rays;
+    const float scale = 2.0f * weight / count;
+    for (int64_t r = gtid >> 6; r < n_rays; r += n_threads >> 6) {
+        RaySums o = composite_ray(rgb, rgb_stride, sigma, sigma_stride, z, rays_d, r, S, lane, nullptr);
+        if (white_bkgd) {
+            const float bg = __fsub_rn(1.0f, o.acc);
+            o.r = __fadd_rn(o.r, bg); o.g = __fadd_rn(o.g, bg); o.b = __fadd_rn(o.b, bg);
         }
-        // pass 2, back to front
-        float carry = 0.0f;                                  // sum of w_j v_j over all later segments
-        for (int k = n_seg - 1; k >= 0; --k) {
-            float alpha, e, dist, f, zc; bool valid; int64_t i;
-            sample(64 * k, alpha, e, dist, f, zc, valid, i);
-            const float incl = wave_incl_prod(f, lane);
-            float excl = __shfl_up(incl, 1, 64);
-            if (lane == 0) excl = 1.0f;
-            const float T = __fmul_rn(seg_T[wv][k], excl);
-            const float w = __fmul_rn(alpha, T);
-            float v = 0.0f, cr = 0.0f, cg = 0.0f, cb = 0.0f;
-            if (valid) {
-                cr = rgb[i * rgb_stride]; cg = rgb[i * rgb_stride + 1]; cb = rgb[i * rgb_stride + 2];
-                v = __fadd_rn(__fadd_rn(__fmul_rn(gr, cr), __fmul_rn(gg, cg)), __fmul_rn(gb, cb));
-                v = __fadd_rn(v, __fmul_rn(gd, zc));
-                if (g_w) v = __fadd_rn(v, g_w[i]);
-                v = __fsub_rn(v, bg);
-            }
-            const float wv_ = valid ? __fmul_rn(w, v) : 0.0f;
-            const float incl_rev = wave_incl_sum_rev(wv_, lane);
-            const float suffix = __fadd_rn(__fsub_rn(incl_rev, wv_), carry);     // strictly later samples
-            carry = __fadd_rn(carry, __shfl(incl_rev, 0, 64));
-            if (valid) {
-                const float d_alpha = __fsub_rn(__fmul_rn(T, v), suffix / f);
-                const float sg = sigma[i * sigma_stride];
-                d_sigma[i * d_sigma_stride] = sg > 0.0f ? __fmul_rn(__fmul_rn(d_alpha, dist), e) : 0.0f;
-                d_rgb[i * d_rgb_stride] = __fmul_rn(w, gr);
-                d_rgb[i * d_rgb_stride + 1] = __fmul_rn(w, gg);
-                d_rgb[i * d_rgb_stride + 2] = __fmul_rn(w, gb);
-            }
+        const float dr = o.r - target[r * 3], dg = o.g - target[r * 3 + 1], db = o.b - target[r * 3 + 2];
+        if (lane == 0) {
+            if (pred) { pred[r * 3] = o.r; pred[r * 3 + 1] = o.g; pred[r * 3 + 2] = o.b; }
+            ray_loss[r] = dr * dr + dg * dg + db * db;
         }
+        composite_backward_ray(rgb, rgb_stride, sigma, sigma_stride, z, rays_d, r, S, lane, white_bkgd, scale * dr, scale * dg, scale * db, 0.0f,
+                               nullptr, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, seg_T[wv]);
+    }
+    // the last workgroup to arrive adds up the rays' squared errors (threadfence + ticket: every ray_loss store of a workgroup is
+    // visible device-wide before its ticket is drawn)
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) ticket_s = atomicAdd(ticket, 1u);
+    __syncthreads();
+    if (ticket_s != gridDim.x - 1) return;
+    __threadfence();
+    float t = 0.0f;
+    for (int64_t r = threadIdx.x; r < n_rays; r += kBlock) t += __hip_atomic_load(ray_loss + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    if (lane == 0) part[wv] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = 0.0f;
+        for (int k = 0; k < kBlock / 64; ++k) tot += part[k];
+        *loss = weight * tot / count;
+        *ticket = 0u;                                    // ready for the next launch on the same stream
     }
 }
 
@@ -526,6 +607,18 @@ __global__ void __launch_bounds__(1024) mse_grad_kernel(const float* __restrict_
         for (int k = 0; k < 16; ++k) t += part[k];
         *loss = weight * t / (float)n;
     }
+}
+
+int launch_composite_mse_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
+                                  int64_t n_rays, int S, int white_bkgd, const float* target, float weight, float* pred, float* d_rgb,
+                                  int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* loss, uint32_t* ticket, float* zero_buf,
+                                  int64_t zero_n, hipStream_t s) {
+    if (n_rays <= 0 || S > 64 * kMaxSegments) return NRF_EINVAL;
+    const int64_t work = std::max(n_rays * 64, (zero_n + 3) / 4);
+    hipLaunchKernelGGL(composite_mse_backward_kernel, dim3(grid_for(work, kBlock, 16384)), dim3(kBlock), 0, s, rgb, rgb_stride, sigma,
+                       sigma_stride, z, rays_d, n_rays, S, white_bkgd, target, weight, pred, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, ray_loss,
+                       loss, ticket, zero_buf, zero_n);
+    return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 
 int launch_mse_grad(const float* pred, const float* target, int64_t n, float weight, float* g_pred, float* loss, hipStream_t s) {

@@ -500,8 +500,8 @@ def all_reduce_gradients(model, group=None, average=True):
 class FusedStep:
     """The body of the reference's inner loop -- render a batch of rays, `rgb_weight * mse(pred['rgb'], target)`
     (train.py:36-44,280-288; train_minimal.py:102-123), backward, Adam -- as a fixed sequence of libnerfhip calls on
-    preallocated buffers: saving forward -> composite -> d(mse) -> composite backward -> dZ chain + weight gradients ->
-    Adam -> (next step) device re-pack.  Same kernels and the same numbers as the autograd route; what it saves is the
+    preallocated buffers: saving forward -> [composite, mse and its gradient, composite backward: one launch] -> dZ chain +
+    weight gradients -> Adam -> (next step) device re-pack.  Same kernels and the same numbers as the autograd route; what it saves is the
     autograd graph, the per-parameter gradient tensors and the Python between the launches, which at the reference's batch
     sizes (1-2 k rays x 32-64 samples) cost more than the kernels.
 
@@ -536,7 +536,9 @@ class FusedStep:
             self.ctx = torch.empty(max(int(nbytes), 1), dtype=torch.uint8, device=dev)
             self.nbytes = nbytes
             self.out4, self.d_out4 = f(n, 4), f(n, 4)                 # V1: [rgb, sigma] rows; V2: rgb | density packed in the same rows
-            self.pred, self.g_pred = f(R, 3), f(R, 3)
+            self.pred = f(R, 3)
+            self.ray_loss = f(R)
+            self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)     # nrf_composite_mse_backward's counter: zero between launches
             self.grad = torch.zeros(self.model.flat_params().flat.numel(), dtype=torch.float32, device=dev)
             self._key = key
 
@@ -566,26 +568,18 @@ class FusedStep:
                 dirs_d = L.dev_f32(dirs, dev).reshape(n, 3)
                 dino_d = L.dev_f32(dino, dev).reshape(n, m.dino_dim) if m.net == L.NRF_NET_V3 else None
                 L.check(lib.nrf_mlp_forward_train(h, mode, L.ptr(pts), L.ptr(dirs_d), L.ptr(dino_d), n, L.ptr(rgb), L.ptr(den), ctx, self.nbytes, st))
-                L.check(lib.nrf_composite(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(self.pred), None, None, st))
+                heads = (L.ptr(rgb), 3, L.ptr(den), 1)
+                d_heads = (L.ptr(g_rgb), 3, L.ptr(g_den), 1)
             else:
                 L.check(lib.nrf_mlp_forward_train_v1(h, mode, L.ptr(pts), n, L.ptr(o4), ctx, self.nbytes, st))
-                L.check(lib.nrf_composite(L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, self.white,
-                                          L.ptr(self.pred), None, None, st))
-            # loss = w * mean((pred - target)^2) over R*3 elements; d loss / d pred = 2 w (pred - target) / (3 R)
-            if 3 * R <= (1 << 22):
-                loss = torch.empty((), dtype=torch.float32, device=dev)
-                L.check(lib.nrf_mse_grad(L.ptr(self.pred), L.ptr(tgt), 3 * R, self.rgb_weight, L.ptr(self.g_pred), L.ptr(loss), st))
-            else:
-                torch.sub(self.pred, tgt, out=self.g_pred)
-                loss = self.g_pred.square().mean() * self.rgb_weight
-                self.g_pred.mul_(2.0 * self.rgb_weight / (3 * R))
-            if v2:
-                L.check(lib.nrf_composite_backward(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(self.g_pred), None, None,
-                                                   L.ptr(g_rgb), 3, L.ptr(g_den), 1, st))
-            else:
-                L.check(lib.nrf_composite_backward(L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4, L.ptr(z), L.ptr(d), R, S, self.white,
-                                                   L.ptr(self.g_pred), None, None, L.ptr(d4), 4, C.c_void_p(d4.data_ptr() + 12), 4, st))
-            self.grad.zero_()
+                heads = (L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4)
+                d_heads = (L.ptr(d4), 4, C.c_void_p(d4.data_ptr() + 12), 4)
+            # compositor -> loss = w * mean((pred - target)^2) over R*3 elements, d loss / d pred = 2 w (pred - target) / (3 R) ->
+            # compositor backward, and the flat gradient vector cleared: one launch (a ray's loss gradient needs only its own prediction)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(tgt), self.rgb_weight, L.ptr(self.pred),
+                                                   *d_heads, L.ptr(self.ray_loss), L.ptr(loss), L.ptr(self.ticket), L.ptr(self.grad),
+                                                   self.grad.numel(), st))
             if v2:
                 L.check(lib.nrf_mlp_backward(h, mode, L.ptr(rgb), L.ptr(den), L.ptr(g_rgb), L.ptr(g_den), n, ctx, self.nbytes, L.ptr(self.grad), st))
             else:

@@ -926,6 +926,57 @@ def test_mse_grad_kernel_matches_torch(N, n):
     assert (g - pred.grad).abs().max() < 1e-7
 
 
+@pytest.mark.parametrize("R,S,opaque,white,packed", [(257, 32, False, False, True), (64, 64, True, False, False), (100, 100, True, True, True),
+                                                     (33, 200, False, True, False), (1, 1, False, False, True), (5000, 8, True, False, False)])
+def test_composite_mse_backward_equals_the_three_calls(N, R, S, opaque, white, packed):
+    """nrf_composite_mse_backward (FusedStep's one launch between the two network kernels) against nrf_composite -> nrf_mse_grad ->
+    nrf_composite_backward: prediction and both gradients bit-equal (same per-ray bodies), the loss to fp32 summation-order noise;
+    the side job clears the caller's gradient vector; the ticket is left zero, so the call can be repeated."""
+    from nerf_few_shot_limitations_amd import _lib as L
+    import ctypes as C
+    rgb, sig, z, d = composite_case(R, S, 71, opaque and S >= 3)
+    tgt = torch.from_numpy(O.uniform01(72, R * 3).reshape(R, 3)).float().cuda()
+    z, d = z.cuda().contiguous(), d.cuda().contiguous()
+    n = R * S
+    if packed:                                                 # V1 rows [r, g, b, sigma]
+        o4 = torch.cat([rgb, sig], -1).reshape(n, 4).cuda().contiguous()
+        heads = (L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4)
+        new = lambda: torch.full((n, 4), float("nan"), device="cuda")
+        d_heads = lambda t: (L.ptr(t), 4, C.c_void_p(t.data_ptr() + 12), 4)
+    else:                                                      # V2 / V3: rgb (n,3) | density (n,1)
+        c3, s1 = rgb.reshape(n, 3).cuda().contiguous(), sig.reshape(n, 1).cuda().contiguous()
+        heads = (L.ptr(c3), 3, L.ptr(s1), 1)
+        new = lambda: torch.full((4 * n,), float("nan"), device="cuda")
+        d_heads = lambda t: (L.ptr(t[:3 * n]), 3, L.ptr(t[3 * n:]), 1)
+    lib, st, w = L.lib(), L.stream_ptr(), 0.7
+    pred_a, g_pred, loss_a, da = torch.empty(R, 3, device="cuda"), torch.empty(R, 3, device="cuda"), torch.empty((), device="cuda"), new()
+    L.check(lib.nrf_composite(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(pred_a), None, None, st))
+    L.check(lib.nrf_mse_grad(L.ptr(pred_a), L.ptr(tgt), 3 * R, w, L.ptr(g_pred), L.ptr(loss_a), st))
+    L.check(lib.nrf_composite_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(g_pred), None, None, *d_heads(da), st))
+    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ray_loss = torch.empty(R, device="cuda")
+    for rep in range(2):                                       # twice on the same ticket
+        pred_b, loss_b, db = torch.empty(R, 3, device="cuda"), torch.empty((), device="cuda"), new()
+        junk = torch.full((100003,), 3.0, device="cuda")
+        L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, L.ptr(pred_b), *d_heads(db),
+                                               L.ptr(ray_loss), L.ptr(loss_b), L.ptr(ticket), L.ptr(junk), junk.numel() - 3, st))
+        torch.cuda.synchronize()
+        assert torch.equal(pred_a, pred_b)
+        assert torch.equal(da.view(torch.int32), db.view(torch.int32))                  # incl. the untouched (NaN) gaps: nothing else is written
+        assert abs(loss_a.item() - loss_b.item()) <= 2e-6 * max(abs(loss_a.item()), 1e-3)
+        assert int(ticket.item()) == 0
+        assert float(junk[:-3].abs().max()) == 0.0 and torch.equal(junk[-3:], torch.full((3,), 3.0, device="cuda"))
+    # pred may be omitted; bad arguments are refused before any launch
+    L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db), L.ptr(ray_loss),
+                                           L.ptr(loss_b), L.ptr(ticket), None, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(da.view(torch.int32), db.view(torch.int32))
+    assert lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db), L.ptr(ray_loss),
+                                          L.ptr(loss_b), None, None, 0, st) == -1
+    assert lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db), L.ptr(ray_loss),
+                                          L.ptr(loss_b), L.ptr(ticket), None, 5, st) == -1
+
+
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
 def test_gradient_is_additive_over_the_batch_at_scale(N, mode):
     """Size-independent property at a batch no CPU check could cover (131 072 samples, 8-wave kernels in bf16): every

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(L):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in nerfhip.h but not exported"
     assert declared == set(L.SIGNATURES), (declared ^ set(L.SIGNATURES))
-    assert lib.nrf_abi_version() == 4
+    assert lib.nrf_abi_version() == 5
     import ctypes
     for which, st in enumerate((L.nrf_arch, L.nrf_linear, L.nrf_dino, L.nrf_render_opts)):
         assert lib.nrf_abi_sizeof(which) == ctypes.sizeof(st)

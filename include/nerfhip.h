@@ -293,22 +293,26 @@ int nrf_mse_grad(const float* pred, const float* target, int64_t n, float weight
 
 /* nrf_composite + nrf_mse_grad + nrf_composite_backward in ONE launch (the three steps between the network's forward and its
  * backward in the reference's train_step, train.py:236,36-44,285): a ray's loss gradient needs only its own prediction and
- * target.  d_rgb / d_sigma are bit-equal to the three-call sequence; pred (n_rays,3) may be NULL.
- *   ray_loss : n_rays floats of scratch (the rays' squared errors);
- *   loss     : receives weight * mean((pred - target)^2) over 3 n_rays values, summed in a fixed order;
- *   ticket   : one 32-bit counter of device memory that must be ZERO before the first launch and is left zero by every launch
- *              (launches sharing a ticket must be ordered on one stream);
+ * target -- d loss / d pred = 2 weight (pred - target) / (3 n_rays).  d_rgb / d_sigma are bit-equal to the three-call sequence;
+ * pred (n_rays,3) may be NULL.
+ *   ray_loss : n_rays floats, receives each ray's squared error; the loss is weight * sum(ray_loss) / (3 n_rays)
+ *              (nrf_adam_step_loss adds them up in a fixed order as a side job of its launch);
  *   zero_buf : optional, zero_n floats cleared by the same launch (the flat gradient vector nrf_mlp_backward* adds into). */
 int nrf_composite_mse_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride,
                                const float* z_vals, const float* rays_d, int64_t n_rays, int n_samples, int white_bkgd,
                                const float* target, float weight, float* pred,
                                float* d_rgb, int d_rgb_stride, float* d_sigma, int d_sigma_stride,
-                               float* ray_loss, float* loss, uint32_t* ticket, float* zero_buf, int64_t zero_n, void* stream);
+                               float* ray_loss, float* zero_buf, int64_t zero_n, void* stream);
 
 /* torch.optim.Adam's update (train.py:113-118; no amsgrad) on flat vectors;
  * step counts from 1. */
 int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
                   float lr, float beta1, float beta2, float eps, float weight_decay, int step, void* stream);
+/* The same update, and as a side job of the launch loss[0] = loss_weight * sum(ray_loss[0..n_rays)) / (3 n_rays), summed in a
+ * fixed order (ray_loss: nrf_composite_mse_backward's per-ray squared errors). */
+int nrf_adam_step_loss(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                       const float* ray_loss, int64_t n_rays, float loss_weight, float* loss, void* stream);
 
 #ifdef __cplusplus
 }

@@ -94,9 +94,11 @@ SIGNATURES = {
     "nrf_mse_grad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "nrf_composite_mse_backward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                              C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+                                             C.c_int64, C.c_void_p]),
     "nrf_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
                                 C.c_float, C.c_int, C.c_void_p]),
+    "nrf_adam_step_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float,
+                                     C.c_float, C.c_int, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None

@@ -604,14 +604,14 @@ int nrf_mse_grad(const float* pred, const float* target, int64_t n, float weight
 
 int nrf_composite_mse_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z_vals, const float* rays_d,
                                int64_t n_rays, int n_samples, int white_bkgd, const float* target, float weight, float* pred, float* d_rgb,
-                               int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* loss, uint32_t* ticket, float* zero_buf,
-                               int64_t zero_n, void* stream) {
+                               int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* zero_buf, int64_t zero_n,
+                               void* stream) {
     if (n_rays <= 0 || n_rays > ((int64_t)1 << 30) || n_samples < 1 || n_samples > 4096) return fail(NRF_EINVAL, "nrf_composite_mse_backward: bad sizes");
     if (rgb_stride < 3 || sigma_stride < 1 || d_rgb_stride < 3 || d_sigma_stride < 1) return fail(NRF_EINVAL, "bad strides");
-    if (!rgb || !sigma || !z_vals || !rays_d || !target || !d_rgb || !d_sigma || !ray_loss || !loss || !ticket) return fail(NRF_EINVAL, "null pointer");
+    if (!rgb || !sigma || !z_vals || !rays_d || !target || !d_rgb || !d_sigma || !ray_loss) return fail(NRF_EINVAL, "null pointer");
     if (zero_n < 0 || (zero_n > 0 && !zero_buf)) return fail(NRF_EINVAL, "zero_buf is NULL");
     const int r = nrf::launch_composite_mse_backward(rgb, rgb_stride, sigma, sigma_stride, z_vals, rays_d, n_rays, n_samples, white_bkgd, target,
-                                                     weight, pred, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, ray_loss, loss, ticket, zero_buf, zero_n,
+                                                     weight, pred, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, ray_loss, zero_buf, zero_n,
                                                      (hipStream_t)stream);
     return r == NRF_OK ? NRF_OK : fail(r, "composite + mse + backward launch failed");
 }
@@ -622,7 +622,20 @@ int nrf_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
     if (n == 0) return NRF_OK;
     if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(NRF_EINVAL, "null pointer");
     if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps >= 0.0f)) return fail(NRF_EINVAL, "bad Adam constants");
-    const int r = nrf::launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream);
+    const int r = nrf::launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, 0, 0.0f, nullptr,
+                                   (hipStream_t)stream);
+    return r == NRF_OK ? NRF_OK : fail(r, "adam launch failed");
+}
+
+int nrf_adam_step_loss(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, const float* ray_loss, int64_t n_rays, float loss_weight, float* loss,
+                       void* stream) {
+    if (n <= 0 || step < 1) return fail(NRF_EINVAL, "bad n / step");
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return fail(NRF_EINVAL, "null pointer");
+    if (!(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps >= 0.0f)) return fail(NRF_EINVAL, "bad Adam constants");
+    if (!ray_loss || !loss || n_rays <= 0) return fail(NRF_EINVAL, "nrf_adam_step_loss: ray_loss / loss missing");
+    const int r = nrf::launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, ray_loss, n_rays, loss_weight,
+                                   loss, (hipStream_t)stream);
     return r == NRF_OK ? NRF_OK : fail(r, "adam launch failed");
 }
 

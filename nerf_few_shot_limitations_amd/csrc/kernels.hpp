@@ -110,11 +110,11 @@ int launch_train_backward_v3(const DeviceNet& net, const TrainDev& t, int mma_mo
                              const float* g_rgb, const float* g_density, int64_t n, void* ctx, float* grad, hipStream_t s, std::string& err);
 int launch_repack(const float* flat, const int32_t* src, int64_t n_elems, int mma_mode, void* out, hipStream_t s);
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                hipStream_t s);
+                const float* ray_loss, int64_t n_rays, float loss_weight, float* loss, hipStream_t s);
 int launch_mse_grad(const float* pred, const float* target, int64_t n, float weight, float* g_pred, float* loss, hipStream_t s);
 int launch_composite_mse_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
                                   int64_t n_rays, int S, int white_bkgd, const float* target, float weight, float* pred, float* d_rgb,
-                                  int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* loss, uint32_t* ticket, float* zero_buf,
+                                  int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* zero_buf,
                                   int64_t zero_n, hipStream_t s);
 int launch_repack3(const float* flat, const int32_t* const src[3], const int64_t n_elems[3], const int modes[3], void* const out[3], hipStream_t s);
 int launch_composite_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,

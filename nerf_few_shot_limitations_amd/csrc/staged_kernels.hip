@@ -263,21 +263,19 @@ __global__ void __launch_bounds__(kBlock) composite_backward_kernel(const float*
 // The three launches between the network's forward and its backward in a FusedStep -- compositor, `rgb_weight * nn.MSELoss()` with
 // its gradient, compositor backward (train.py:236,36-44,285) -- as ONE: the loss gradient of a ray needs nothing but the ray's own
 // prediction and target, d loss / d pred = 2 w (pred - target) / (3 R).  Same per-ray arithmetic as the three kernels (the two bodies
-// above), so d_rgb / d_sigma are bit-equal to the staged sequence.  The loss VALUE is summed in a fixed order (per-ray squared errors
-// in `ray_loss`, added by the last workgroup to finish: thread t takes rays t, t + 256, ..., then one butterfly and four partial
-// sums) -- reproducible run to run, not bit-equal to mse_grad_kernel's order.  Side job: `zero_buf` (the caller's flat gradient
-// vector, which the weight-gradient reduction adds into) is cleared by the same launch.
+// above), so d_rgb / d_sigma are bit-equal to the staged sequence.  The loss VALUE needs all rays: every ray leaves its squared error
+// in `ray_loss` and a later launch adds them up in a fixed order (adam_kernel's side job, train_v1.hip) -- a device-wide
+// "last workgroup sums" inside this kernel costs a release fence (an L2 write-back on this chip) per workgroup: measured 53 us
+// against 16 us for the three separate launches.  Side job: `zero_buf` (the caller's flat gradient vector, which the
+// weight-gradient reduction adds into) is cleared by the same launch.
 __global__ void __launch_bounds__(kBlock) composite_mse_backward_kernel(const float* __restrict__ rgb, int rgb_stride,
                                                                         const float* __restrict__ sigma, int sigma_stride,
                                                                         const float* __restrict__ z, const float* __restrict__ rays_d,
                                                                         int64_t n_rays, int S, int white_bkgd, const float* __restrict__ target,
                                                                         float weight, float* __restrict__ pred, float* __restrict__ d_rgb,
                                                                         int d_rgb_stride, float* __restrict__ d_sigma, int d_sigma_stride,
-                                                                        float* __restrict__ ray_loss, float* __restrict__ loss, unsigned* __restrict__ ticket,
-                                                                        float* __restrict__ zero_buf, int64_t zero_n) {
+                                                                        float* __restrict__ ray_loss, float* __restrict__ zero_buf, int64_t zero_n) {
     __shared__ float seg_T[kBlock / 64][kMaxSegments];
-    __shared__ float part[kBlock / 64];
-    __shared__ unsigned ticket_s;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t gtid = blockIdx.x * (int64_t)kBlock + threadIdx.x, n_threads = (int64_t)gridDim.x * kBlock;
     for (int64_t i = gtid; i < zero_n; i += n_threads) zero_buf[i] = 0.0f;
@@ -297,26 +295,8 @@ __global__ void __launch_bounds__(kBlock) composite_mse_backward_kernel(const fl
         composite_backward_ray(rgb, rgb_stride, sigma, sigma_stride, z, rays_d, r, S, lane, white_bkgd, scale * dr, scale * dg, scale * db, 0.0f,
                                nullptr, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, seg_T[wv]);
     }
-    // the last workgroup to arrive adds up the rays' squared errors (threadfence + ticket: every ray_loss store of a workgroup is
-    // visible device-wide before its ticket is drawn)
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) ticket_s = atomicAdd(ticket, 1u);
-    __syncthreads();
-    if (ticket_s != gridDim.x - 1) return;
-    __threadfence();
-    float t = 0.0f;
-    for (int64_t r = threadIdx.x; r < n_rays; r += kBlock) t += __hip_atomic_load(ray_loss + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = wave_sum(t);
-    if (lane == 0) part[wv] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float tot = 0.0f;
-        for (int k = 0; k < kBlock / 64; ++k) tot += part[k];
-        *loss = weight * tot / count;
-        *ticket = 0u;                                    // ready for the next launch on the same stream
-    }
 }
+
 
 // ---- a3: ray_utils.py:86-143 (intent) --------------------------------------------------------
 // One WAVE per ray, LANE <-> sample: the rows of z, weights, the new samples and the union are read and written as contiguous
@@ -611,13 +591,13 @@ __global__ void __launch_bounds__(1024) mse_grad_kernel(const float* __restrict_
 
 int launch_composite_mse_backward(const float* rgb, int rgb_stride, const float* sigma, int sigma_stride, const float* z, const float* rays_d,
                                   int64_t n_rays, int S, int white_bkgd, const float* target, float weight, float* pred, float* d_rgb,
-                                  int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* loss, uint32_t* ticket, float* zero_buf,
+                                  int d_rgb_stride, float* d_sigma, int d_sigma_stride, float* ray_loss, float* zero_buf,
                                   int64_t zero_n, hipStream_t s) {
     if (n_rays <= 0 || S > 64 * kMaxSegments) return NRF_EINVAL;
     const int64_t work = std::max(n_rays * 64, (zero_n + 3) / 4);
     hipLaunchKernelGGL(composite_mse_backward_kernel, dim3(grid_for(work, kBlock, 16384)), dim3(kBlock), 0, s, rgb, rgb_stride, sigma,
                        sigma_stride, z, rays_d, n_rays, S, white_bkgd, target, weight, pred, d_rgb, d_rgb_stride, d_sigma, d_sigma_stride, ray_loss,
-                       loss, ticket, zero_buf, zero_n);
+                       zero_buf, zero_n);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 

@@ -67,10 +67,35 @@ __global__ void __launch_bounds__(256) repack3_kernel(const float* __restrict__ 
 
 // torch.optim.Adam (train.py:113-118; no amsgrad, weight decay added to the gradient, bias-corrected moments):
 //   g += wd*p; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// Side job (FusedStep): the loss VALUE of the step, loss_weight * mean over 3 n_rays values = loss_weight * sum(ray_loss) / (3 n_rays)
+// with the rays' squared errors left by composite_mse_backward_kernel, added by the last workgroup in a fixed order (thread t: rays
+// t, t + 256, ...; one butterfly; four partial sums): reproducible run to run.
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                   float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps,
-                                                  float wd, float bc1, float bc2_sqrt) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+                                                  float wd, float bc1, float bc2_sqrt, const float* __restrict__ ray_loss, int64_t n_rays,
+                                                  float loss_weight, float* __restrict__ loss) {
+    const int extra = ray_loss ? 1 : 0;
+    if (extra && blockIdx.x == 0) {                       // one workgroup more than the update needs, the first to start: it does nothing else
+        __shared__ float part[4];
+        float t = 0.0f;
+        int64_t r = threadIdx.x;
+        for (; r + 7 * 256 < n_rays; r += 8 * 256) {      // eight loads in flight, added in order
+            float q[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) q[k] = ray_loss[r + k * 256];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += q[k];
+        }
+        for (; r < n_rays; r += 256) t += ray_loss[r];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_xor(t, d, 64);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) *loss = loss_weight * (((part[0] + part[1]) + part[2]) + part[3]) / (3.0f * (float)n_rays);
+        return;
+    }
+    const int64_t stride = (int64_t)(gridDim.x - extra) * blockDim.x;
+    for (int64_t i = (blockIdx.x - extra) * (int64_t)blockDim.x + threadIdx.x; i < n; i += stride) {
         float gi = g[i];
         const float pi = p[i];
         if (wd != 0.0f) gi = __fadd_rn(gi, __fmul_rn(wd, pi));
@@ -303,12 +328,13 @@ int launch_repack3(const float* flat, const int32_t* const src[3], const int64_t
 }
 
 int launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd, int step,
-                hipStream_t s) {
+                const float* ray_loss, int64_t n_rays, float loss_weight, float* loss, hipStream_t s) {
     if (n <= 0) return NRF_OK;
     const float bc1 = 1.0f - powf(b1, (float)step);
     const float bc2_sqrt = sqrtf(1.0f - powf(b2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
-                       wd, bc1, bc2_sqrt);
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096) + (ray_loss ? 1u : 0u);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, lr, b1, b2, eps,
+                       wd, bc1, bc2_sqrt, ray_loss, n_rays, loss_weight, loss);
     return hipGetLastError() == hipSuccess ? NRF_OK : NRF_EHIP;
 }
 

@@ -538,7 +538,6 @@ class FusedStep:
             self.out4, self.d_out4 = f(n, 4), f(n, 4)                 # V1: [rgb, sigma] rows; V2: rgb | density packed in the same rows
             self.pred = f(R, 3)
             self.ray_loss = f(R)
-            self.ticket = torch.zeros(1, dtype=torch.int32, device=dev)     # nrf_composite_mse_backward's counter: zero between launches
             self.grad = torch.zeros(self.model.flat_params().flat.numel(), dtype=torch.float32, device=dev)
             self._key = key
 
@@ -574,12 +573,11 @@ class FusedStep:
                 L.check(lib.nrf_mlp_forward_train_v1(h, mode, L.ptr(pts), n, L.ptr(o4), ctx, self.nbytes, st))
                 heads = (L.ptr(o4), 4, C.c_void_p(o4.data_ptr() + 12), 4)
                 d_heads = (L.ptr(d4), 4, C.c_void_p(d4.data_ptr() + 12), 4)
-            # compositor -> loss = w * mean((pred - target)^2) over R*3 elements, d loss / d pred = 2 w (pred - target) / (3 R) ->
-            # compositor backward, and the flat gradient vector cleared: one launch (a ray's loss gradient needs only its own prediction)
+            # compositor -> d loss / d pred = 2 w (pred - target) / (3 R) -> compositor backward, and the flat gradient vector cleared:
+            # one launch (a ray's loss gradient needs only its own prediction); the rays' squared errors stay in ray_loss
             loss = torch.empty((), dtype=torch.float32, device=dev)
             L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, self.white, L.ptr(tgt), self.rgb_weight, L.ptr(self.pred),
-                                                   *d_heads, L.ptr(self.ray_loss), L.ptr(loss), L.ptr(self.ticket), L.ptr(self.grad),
-                                                   self.grad.numel(), st))
+                                                   *d_heads, L.ptr(self.ray_loss), L.ptr(self.grad), self.grad.numel(), st))
             if v2:
                 L.check(lib.nrf_mlp_backward(h, mode, L.ptr(rgb), L.ptr(den), L.ptr(g_rgb), L.ptr(g_den), n, ctx, self.nbytes, L.ptr(self.grad), st))
             else:
@@ -589,7 +587,9 @@ class FusedStep:
             opt = self.opt
             fp, flat = opt._buffers()
             opt.step_count += 1
-            L.check(lib.nrf_adam_step(L.ptr(flat), L.ptr(self.grad), L.ptr(opt.exp_avg), L.ptr(opt.exp_avg_sq), flat.numel(), opt.lr, opt.betas[0],
-                                      opt.betas[1], opt.eps, opt.weight_decay, opt.step_count, st))
+            # Adam, and as a side job of its launch the loss value: rgb_weight * sum(ray_loss) / (3 R) in a fixed order
+            L.check(lib.nrf_adam_step_loss(L.ptr(flat), L.ptr(self.grad), L.ptr(opt.exp_avg), L.ptr(opt.exp_avg_sq), flat.numel(), opt.lr,
+                                           opt.betas[0], opt.betas[1], opt.eps, opt.weight_decay, opt.step_count, L.ptr(self.ray_loss), R,
+                                           self.rgb_weight, L.ptr(loss), st))
         m._gen += 1
         return loss

@@ -930,8 +930,9 @@ def test_mse_grad_kernel_matches_torch(N, n):
                                                      (33, 200, False, True, False), (1, 1, False, False, True), (5000, 8, True, False, False)])
 def test_composite_mse_backward_equals_the_three_calls(N, R, S, opaque, white, packed):
     """nrf_composite_mse_backward (FusedStep's one launch between the two network kernels) against nrf_composite -> nrf_mse_grad ->
-    nrf_composite_backward: prediction and both gradients bit-equal (same per-ray bodies), the loss to fp32 summation-order noise;
-    the side job clears the caller's gradient vector; the ticket is left zero, so the call can be repeated."""
+    nrf_composite_backward: prediction and both gradients bit-equal (same per-ray bodies); the side job clears the caller's gradient
+    vector; the loss, added up from ray_loss by nrf_adam_step_loss's side job, to fp32 summation-order noise -- and the Adam update
+    of that launch is nrf_adam_step's, bit for bit."""
     from nerf_few_shot_limitations_amd import _lib as L
     import ctypes as C
     rgb, sig, z, d = composite_case(R, S, 71, opaque and S >= 3)
@@ -953,28 +954,40 @@ def test_composite_mse_backward_equals_the_three_calls(N, R, S, opaque, white, p
     L.check(lib.nrf_composite(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(pred_a), None, None, st))
     L.check(lib.nrf_mse_grad(L.ptr(pred_a), L.ptr(tgt), 3 * R, w, L.ptr(g_pred), L.ptr(loss_a), st))
     L.check(lib.nrf_composite_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(g_pred), None, None, *d_heads(da), st))
-    ticket = torch.zeros(1, dtype=torch.int32, device="cuda")
     ray_loss = torch.empty(R, device="cuda")
-    for rep in range(2):                                       # twice on the same ticket
-        pred_b, loss_b, db = torch.empty(R, 3, device="cuda"), torch.empty((), device="cuda"), new()
-        junk = torch.full((100003,), 3.0, device="cuda")
-        L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, L.ptr(pred_b), *d_heads(db),
-                                               L.ptr(ray_loss), L.ptr(loss_b), L.ptr(ticket), L.ptr(junk), junk.numel() - 3, st))
-        torch.cuda.synchronize()
-        assert torch.equal(pred_a, pred_b)
-        assert torch.equal(da.view(torch.int32), db.view(torch.int32))                  # incl. the untouched (NaN) gaps: nothing else is written
-        assert abs(loss_a.item() - loss_b.item()) <= 2e-6 * max(abs(loss_a.item()), 1e-3)
-        assert int(ticket.item()) == 0
-        assert float(junk[:-3].abs().max()) == 0.0 and torch.equal(junk[-3:], torch.full((3,), 3.0, device="cuda"))
-    # pred may be omitted; bad arguments are refused before any launch
-    L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db), L.ptr(ray_loss),
-                                           L.ptr(loss_b), L.ptr(ticket), None, 0, st))
+    pred_b, db = torch.empty(R, 3, device="cuda"), new()
+    junk = torch.full((100003,), 3.0, device="cuda")
+    L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, L.ptr(pred_b), *d_heads(db),
+                                           L.ptr(ray_loss), L.ptr(junk), junk.numel() - 3, st))
     torch.cuda.synchronize()
-    assert torch.equal(da.view(torch.int32), db.view(torch.int32))
-    assert lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db), L.ptr(ray_loss),
-                                          L.ptr(loss_b), None, None, 0, st) == -1
-    assert lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db), L.ptr(ray_loss),
-                                          L.ptr(loss_b), L.ptr(ticket), None, 5, st) == -1
+    assert torch.equal(pred_a, pred_b)
+    assert torch.equal(da.view(torch.int32), db.view(torch.int32))                  # incl. the untouched (NaN) gaps: nothing else is written
+    assert float(junk[:-3].abs().max()) == 0.0 and torch.equal(junk[-3:], torch.full((3,), 3.0, device="cuda"))
+    assert torch.allclose(ray_loss, (pred_a - tgt).square().sum(-1), rtol=1e-6, atol=1e-12)
+    # the loss through Adam's side job; the update itself equals nrf_adam_step's
+    npar = 70001
+    p0 = torch.from_numpy(O.uniform01(73, npar) - 0.5).float().cuda()
+    g0 = torch.from_numpy(O.uniform01(74, npar) - 0.5).float().cuda()
+    pa, ma, va = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    pb, mb, vb = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    loss_b = torch.empty((), device="cuda")
+    for step in (1, 2):
+        L.check(lib.nrf_adam_step(L.ptr(pa), L.ptr(g0), L.ptr(ma), L.ptr(va), npar, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step, st))
+        L.check(lib.nrf_adam_step_loss(L.ptr(pb), L.ptr(g0), L.ptr(mb), L.ptr(vb), npar, 1e-3, 0.9, 0.999, 1e-8, 1e-6, step, L.ptr(ray_loss), R, w,
+                                       L.ptr(loss_b), st))
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert abs(loss_a.item() - loss_b.item()) <= 2e-6 * max(abs(loss_a.item()), 1e-3)
+    # pred and the side job may be omitted; bad arguments are refused before any launch
+    db2 = new()
+    L.check(lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db2), L.ptr(ray_loss),
+                                           None, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(da.view(torch.int32), db2.view(torch.int32))
+    assert lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db2), None, None, 0, st) == -1
+    assert lib.nrf_composite_mse_backward(*heads, L.ptr(z), L.ptr(d), R, S, int(white), L.ptr(tgt), w, None, *d_heads(db2), L.ptr(ray_loss),
+                                          None, 5, st) == -1
+    assert lib.nrf_adam_step_loss(L.ptr(pb), L.ptr(g0), L.ptr(mb), L.ptr(vb), npar, 1e-3, 0.9, 0.999, 1e-8, 1e-6, 3, None, R, w, L.ptr(loss_b), st) == -1
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f32"])

@@ -134,16 +134,19 @@ def check(code: int) -> None:
 
 
 def ptr(t):
-    """Device pointer of a CUDA(HIP) fp32 contiguous tensor, or None."""
+    """Device pointer of a CUDA(HIP) fp32 contiguous tensor (an int: ctypes converts it for a c_void_p parameter), or None."""
     if t is None:
         return None
     if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
         raise ValueError("expected a contiguous float32 tensor on the GPU")
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()
 
 
 def dev_f32(t, device=None):
     """Bring a tensor-like to contiguous fp32 on the GPU (the reference's callers hand over fp32 tensors)."""
+    if (type(t) is torch.Tensor and t.is_cuda and t.dtype == torch.float32 and not t.requires_grad and t.is_contiguous()
+            and (device is None or t.device == device)):
+        return t                                    # the common case on the training loop's host-bound path: nothing to do
     t = torch.as_tensor(t)
     if device is None:
         device = t.device if t.is_cuda else torch.device("cuda", torch.cuda.current_device())
@@ -166,12 +169,20 @@ def fresh_seed():
 
 
 def stream_ptr():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current device's current stream as the `void* stream` argument (torch's raw-stream accessor: no Stream object per call)."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
+_gpu_seen = False
 
 
 def require_gpu():
+    global _gpu_seen
+    if _gpu_seen:
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("nerf_few_shot_limitations_amd needs an MI355X (gfx950) GPU: no HIP device is visible and there is no CPU path")
+    _gpu_seen = True
 
 
 _ladders = {}

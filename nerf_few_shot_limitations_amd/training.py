@@ -304,7 +304,7 @@ class _RenderFn(torch.autograd.Function):
                 L.check(lib.nrf_mlp_forward_train(h, mode, L.ptr(x), L.ptr(dirs), L.ptr(dino), n, L.ptr(rgb), L.ptr(den), cb, nbytes, st))
                 L.check(lib.nrf_composite(L.ptr(rgb), 3, L.ptr(den), 1, L.ptr(z), L.ptr(d), R, S, white, L.ptr(out_rgb), L.ptr(out_depth), L.ptr(out_w), st))
         ctx.module, ctx.buf, ctx.nbytes, ctx.mode, ctx.white, ctx.v1 = module, buf, nbytes, mode, white, v1
-        ctx.versions = module._versions()
+        ctx.versions = module._packed                    # the versions handle() just packed (== module._versions(), not recomputed)
         ctx.save_for_backward(o4, z, d)
         ctx.set_materialize_grads(False)
         return out_rgb, out_depth, out_w

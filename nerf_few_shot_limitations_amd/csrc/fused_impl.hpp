@@ -131,6 +131,16 @@ __global__ void __launch_bounds__(WAVES * 64) render_kernel(const RenderKArgs P)
     Pipe<WAVES, pinned_walk<Mode, NT>()> pipe;
     pipe.init(P.net.stream, P.net.n_chunks, lds, P.net.ablate);
     pipe.start();
+#ifdef NRF_ABLATE_BUILD
+    // timing experiment (pair with 2 = no barriers, which would re-align the waves): wave w starts w x 16 (512) or w x 64 (1024)
+    // cycles late, so that the four waves no longer reach each LDS-DMA instruction in the same cycle
+    if (P.net.ablate & (512 | 1024)) {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        for (int i = 0; i < w; ++i) {
+            if (P.net.ablate & 512) asm volatile("s_nop 15"); else __builtin_amdgcn_s_sleep(1);
+        }
+    }
+#endif
 
     auto z_base = [&](int s) -> float { return zl[s]; };
     // Samples per ray and MLP pass (host: pick_spw_log2).  The wave's COLS sample columns are RPW = COLS/SPW rays x SPW consecutive

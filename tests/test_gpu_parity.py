@@ -1032,6 +1032,68 @@ def test_randomized_launch_cuts_never_change_a_bit(N, mode):
         assert torch.isfinite(whole["rgb"]).all() and float(whole["weights"].sum(-1).max()) <= 1 + 1e-4
 
 
+def test_poisoned_rays_stay_inside_their_own_rows(N):
+    """NaN / Inf / absurdly large rays, depths, weights and image coordinates: every index on the path (feature-map taps, inverse-cdf
+    searches, merge ranks) comes out of comparisons that a NaN fails, so nothing is read or written out of bounds, the launch
+    completes, and the rows of the CLEAN rays carry the bits of a launch without the bad ones -- fused kernels (plain and ray-queue),
+    V1 / V3, a 16-bit and the fp32 mode; then the staged kernels that index by data."""
+    inf, nan = float("inf"), float("nan")
+    c2w = T(O.LEGO_LIKE_C2W)
+    Hh, Ww, S = 20, 15, 24
+    ro, rd = N.get_rays(Hh, Ww, O.focal_for(Ww), c2w)
+    ro, rd = ro.reshape(-1, 3).clone(), rd.reshape(-1, 3).clone()
+    R = ro.shape[0]
+    bad = [0, 7, 63, 64, 65, 128, 255, R - 1]
+    poison = [(nan, 0), (inf, 1), (-inf, 0), (1e30, 1), (nan, 1), (-1e38, 0), (3e38, 1), (nan, 0)]
+    for i, (v, which) in zip(bad, poison):
+        (ro if which == 0 else rd)[i, i % 3] = v
+    clean = torch.tensor([i for i in range(R) if i not in bad], device="cuda")
+    for variant, mode in (("v1", "f16"), ("v1", "f32"), ("v3", "f16"), ("v3", "f32")):
+        m = {"v1": model_v1, "v3": model_v3}[variant](N, "solid", mode)[0]
+        dino = dict(features=dino_map(), pose=c2w, focal=O.focal_for(Ww), H=Hh, W=Ww) if variant == "v3" else None
+        for eps in (0.0, 1e-2):
+            out = N.render_rays(m, ro, rd, 2.0, 6.0, S, ert_eps=eps, dino=dino)
+            ref = N.render_rays(m, ro[clean], rd[clean], 2.0, 6.0, S, ert_eps=eps, dino=dino)
+            torch.cuda.synchronize()
+            for k in ("rgb", "depth", "weights"):
+                assert torch.equal(out[k][clean], ref[k]), (variant, mode, eps, k)
+                assert torch.isfinite(ref[k]).all()
+    # feature fetch: world points and image coordinates far outside, NaN, Inf -> zeros (grid_sample's zeros padding) or NaN, never a fault
+    feats = dino_map()
+    pts = torch.rand(500, 3, device="cuda") * 2 - 1
+    pts[::7] = torch.tensor([nan, 0.0, 1.0], device="cuda"); pts[1::7] = torch.tensor([inf, -inf, 1e30], device="cuda"); pts[2::7] = 1e38
+    xy = N.project_points_to_image(pts, c2w.cuda(), O.focal_for(Ww), Hh, Ww)
+    if isinstance(xy, tuple):
+        xy = xy[0]
+    f = N.sample_features_at_points(feats, xy)
+    xy2 = torch.rand(500, 2, device="cuda") * 2 - 1
+    xy2[::5] = torch.tensor([nan, inf], device="cuda"); xy2[1::5] = 1e30; xy2[2::5] = -1e30
+    f2 = N.sample_features_at_points(feats, xy2)
+    f2_clean = N.sample_features_at_points(feats, xy2[3::5].contiguous())
+    torch.cuda.synchronize()
+    assert f.shape[0] == 500 and torch.equal(f2[3::5], f2_clean) and float(f2[1::5].abs().max()) == 0.0 and float(f2[2::5].abs().max()) == 0.0
+    # inverse-cdf resampling: NaN / Inf / negative weights, unsorted and NaN depths
+    z = torch.sort(torch.rand(64, 32, device="cuda") * 4 + 2, -1).values
+    w = torch.rand(64, 32, device="cuda")
+    w2, z2 = w.clone(), z.clone()
+    w2[::4, 3] = nan; w2[1::4, 5] = inf; w2[2::4] = -1.0; z2[::8, 10] = nan; z2[4::8] = z2[4::8].flip(-1)
+    smp, uni = N.sample_pdf(z2, w2, 16)
+    smp_c, uni_c = N.sample_pdf(z[3::4].contiguous(), w[3::4].contiguous(), 16)
+    torch.cuda.synchronize()
+    assert torch.equal(smp[3::4], smp_c) and torch.equal(uni[3::4], uni_c)
+    # compositor: NaN / Inf densities stay in their rays
+    rgb, sig = torch.rand(40, 16, 3, device="cuda"), torch.rand(40, 16, 1, device="cuda") * 3
+    sig2 = sig.clone(); sig2[::4, 2] = nan; sig2[1::4, 0] = inf; sig2[2::4, 15] = -inf
+    zc, dc = torch.sort(torch.rand(40, 16, device="cuda") * 4 + 2, -1).values, torch.rand(40, 3, device="cuda") - 0.5
+    vr = N.VolumeRenderer()
+    with torch.no_grad():
+        a = vr(rgb, sig2, zc, dc)
+        b = vr(rgb[3::4].contiguous(), sig[3::4].contiguous(), zc[3::4].contiguous(), dc[3::4].contiguous())
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x[3::4], y)
+
+
 # ------------------------------------------------------------------ a3 hierarchical resampling (parity UNPINNED: vs our oracle only)
 def test_sample_pdf_vs_oracle(N):
     R, S, Ni = 333, 64, 32

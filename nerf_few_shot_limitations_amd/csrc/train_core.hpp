@@ -28,11 +28,26 @@ struct ActIO16 {
 #pragma unroll
         for (int v = 0; v < 2; ++v) *(i32x4*)(p + v * kFragBytes) = __builtin_bit_cast(i32x4, a.f[v]);
     }
+    // the saved tiles in HBM are written once and read once or twice by LATER kernels, hundreds of MB per step: streaming
+    // (non-temporal) accesses keep them from being allocated in the L2 / MALL on their way (same-box A/B, V1 bf16, 2048 x 32:
+    // stores -7.7 % of the step, loads another -3 %; profiles/r03_ab_train_nontemporal.txt)
+    template <class Act>
+    __device__ static __forceinline__ void store_g(char* p, const Act& a) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) __builtin_nontemporal_store(__builtin_bit_cast(i32x4, a.f[v]), (i32x4*)(p + v * kFragBytes));
+    }
     template <class Act>
     __device__ static __forceinline__ Act load(const char* p) {
         Act a;
 #pragma unroll
         for (int v = 0; v < 2; ++v) a.f[v] = __builtin_bit_cast(V8, *(const i32x4*)(p + v * kFragBytes));
+        return a;
+    }
+    template <class Act>
+    __device__ static __forceinline__ Act load_g(const char* p) {
+        Act a;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) a.f[v] = __builtin_bit_cast(V8, __builtin_nontemporal_load((const i32x4*)(p + v * kFragBytes)));
         return a;
     }
 };
@@ -47,11 +62,28 @@ struct ActIO<ModeF32> {
         for (int v = 0; v < 4; ++v) *(f32x4*)(p + v * kFragBytes) = f32x4{a.r[4 * v], a.r[4 * v + 1], a.r[4 * v + 2], a.r[4 * v + 3]};
     }
     template <class Act>
+    __device__ static __forceinline__ void store_g(char* p, const Act& a) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+            __builtin_nontemporal_store(f32x4{a.r[4 * v], a.r[4 * v + 1], a.r[4 * v + 2], a.r[4 * v + 3]}, (f32x4*)(p + v * kFragBytes));
+    }
+    template <class Act>
     __device__ static __forceinline__ Act load(const char* p) {
         Act a;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const f32x4 q = *(const f32x4*)(p + v * kFragBytes);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a.r[4 * v + e] = q[e];
+        }
+        return a;
+    }
+    template <class Act>
+    __device__ static __forceinline__ Act load_g(const char* p) {
+        Act a;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const f32x4 q = __builtin_nontemporal_load((const f32x4*)(p + v * kFragBytes));
 #pragma unroll
             for (int e = 0; e < 4; ++e) a.r[4 * v + e] = q[e];
         }

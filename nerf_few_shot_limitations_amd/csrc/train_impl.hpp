@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_kernel(const TrainKA
 #pragma unroll
             for (int t = 0; t < KT0; ++t) {
                 enc[t][0] = Mode::template to_act<false>(e[t]);
-                IO::store(tile_ptr<Mode>(P, 0, st, t, lane), enc[t][0]);
+                IO::store_g(tile_ptr<Mode>(P, 0, st, t, lane), enc[t][0]);
             }
             i32x4 mw;
             dense<Mode, KT0, HT, 1>(pipe, bias, h, enc, [&](auto m_, f32x16(&acc)[1]) {
@@ -175,7 +175,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_kernel(const TrainKA
                 __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
 
                 put_bits<m>(mw, relu_bits(acc[0]));
-                IO::store(tile_ptr<Mode>(P, 1, st, m, lane), A[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, 1, st, m, lane), A[m][0]);
                 if constexpr (m == HT - 1) *mask_ptr(P, 0, st, lane) = mw;
             });
         }
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_kernel(const TrainKA
                 __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
 
                 put_bits<m>(mw, relu_bits(acc[0]));
-                IO::store(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
                 if constexpr (m == HT - 1) *mask_ptr(P, slot - 1, st, lane) = mw;
             });
         };
@@ -253,13 +253,13 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_kernel(const TrainK
                 e[3] = g.w;                                                         // sigma_out has no activation
             }
             G[0][0] = Mode::template to_act<false>(e);
-            IO::store(tile_ptr<Mode>(P, 2 * n + 1, st, 0, lane), G[0][0]);
+            IO::store_g(tile_ptr<Mode>(P, 2 * n + 1, st, 0, lane), G[0][0]);
         }
         Act A[HT][1], B[HT][1];
         auto epilogue = [&](auto m_, f32x16(&acc)[1], Act (&out)[HT][1], int slot_dz) {
             constexpr int m = decltype(m_)::value;
             out[m][0] = masked_act<Mode, m>(acc[0], mcur);
-            IO::store(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
+            IO::store_g(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
         };
         int below = n - 2;            // mask plane of the layer under the one being produced
         auto prefetch = [&]() { if (below >= 0) mnext = *mask_ptr(P, below, st, lane); --below; };
@@ -355,8 +355,8 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
 #pragma unroll
         for (int q = 0; q < ST; ++q) {
             const bool in = st0 + q < t1;
-            rz[b][q] = (in && has_z) ? IO::template load<Act>(zb + ((st0 + q) * J.dz_stride + wave) * (int64_t)TB) : zero;
-            rx[b][q] = (in && has_x) ? IO::template load<Act>(xb + ((st0 + q) * J.x_stride + J.x_first + wave) * (int64_t)TB) : zero;
+            rz[b][q] = (in && has_z) ? IO::template load_g<Act>(zb + ((st0 + q) * J.dz_stride + wave) * (int64_t)TB) : zero;
+            rx[b][q] = (in && has_x) ? IO::template load_g<Act>(xb + ((st0 + q) * J.x_stride + J.x_first + wave) * (int64_t)TB) : zero;
         }
     };
     // one stage: transpose + park the register set `b`, refill it with the stage PF ahead, multiply
@@ -417,6 +417,8 @@ __global__ void __launch_bounds__(512) weight_grad_kernel(const GradKArgs P) {
             if (col0 + j >= J.KT) continue;
             f32x4* dst = (f32x4*)(part + ((wave * 8 + i * CT + j) * 16) * 64) + lane;
 #pragma unroll
+            // plain stores: the 61 MB of partial sums are read back by the very next kernel and fit the MALL (streaming them -- like
+            // the saved tiles -- made the reduction 2.4 us slower)
             for (int q = 0; q < 4; ++q) dst[q * 64] = f32x4{acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
         }
     }

@@ -47,7 +47,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
 #pragma unroll
             for (int t = 0; t < KT0; ++t) {
                 enc[t][0] = e1[t];
-                IO::store(tile_ptr<Mode>(P, 0, st, t, lane), e1[t]);
+                IO::store_g(tile_ptr<Mode>(P, 0, st, t, lane), e1[t]);
             }
             i32x4 mw;
             dense<Mode, KT0, HT, 1>(pipe, bias, h, enc, [&](auto m_, f32x16(&acc)[1]) {
@@ -55,7 +55,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
                 __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
 
                 put_bits<m>(mw, relu_bits(acc[0]));
-                IO::store(tile_ptr<Mode>(P, 1, st, m, lane), A[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, 1, st, m, lane), A[m][0]);
                 if constexpr (m == HT - 1) *mask_ptr(P, 0, st, lane) = mw;
             });
         }
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
                 __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
 
                 put_bits<m>(mw, relu_bits(acc[0]));
-                IO::store(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
                 if constexpr (m == HT - 1) *mask_ptr(P, slot - 1, st, lane) = mw;
             });
         };
@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
             dense<Mode, HT, HT, 1>(pipe, bias + boff + 32, h, X, [&](auto m_, f32x16(&acc)[1]) {     // feature_head: no activation
                 constexpr int m = decltype(m_)::value;
                 in9[m][0] = Mode::template to_act<false>(acc[0]);
-                IO::store(tile_ptr<Mode>(P, n + 1, st, m, lane), in9[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, n + 1, st, m, lane), in9[m][0]);
             });
             {
                 float dd[3];
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
                 Act t1[pe_tiles(LD)];
                 encode3<Mode, LD>(dd, h, t1);
                 in9[HT][0] = t1[0];
-                IO::store(tile_ptr<Mode>(P, n + 1, st, HT, lane), t1[0]);
+                IO::store_g(tile_ptr<Mode>(P, n + 1, st, HT, lane), t1[0]);
             }
             Act c0[HT / 2][1], c1[HT / 4][1];
             i32x4 mw = {};
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
                 __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
 
                 put_bits<m>(mw, relu_bits(acc[0]));
-                IO::store(tile_ptr<Mode>(P, n + 2, st, m, lane), c0[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, n + 2, st, m, lane), c0[m][0]);
                 if constexpr (m == HT / 2 - 1) *mask_ptr(P, n, st, lane) = mw;
             });
             i32x4 mw1 = {};
@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v2_kernel(const Trai
                 __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
 
                 put_bits<m>(mw1, relu_bits(acc[0]));
-                IO::store(tile_ptr<Mode>(P, n + 3, st, m, lane), c1[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, n + 3, st, m, lane), c1[m][0]);
                 if constexpr (m == HT / 4 - 1) *mask_ptr(P, n + 1, st, lane) = mw1;
             });
             f32x16 rgb[1];
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v2_kernel(const Tra
         auto masked = [&](auto m_, f32x16(&acc)[1], auto& out, int slot_dz) {
             constexpr int m = decltype(m_)::value;
             out[m][0] = masked_act<Mode, m>(acc[0], mcur);
-            IO::store(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
+            IO::store_g(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
         };
 
         Act in9[HT + 1][1];
@@ -183,11 +183,11 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v2_kernel(const Tra
                     ds = P.density[raw] > 0.0f ? P.g_density[raw] : 0.0f;          // relu' of density_head (nerf_mlp.py:63)
                 }
                 G[0][0] = Mode::template to_act<false>(e);
-                IO::store(tile_ptr<Mode>(P, 2 * n + 8, st, 0, lane), G[0][0]);
+                IO::store_g(tile_ptr<Mode>(P, 2 * n + 8, st, 0, lane), G[0][0]);
                 f32x16 e2 = {};
                 e2[0] = ds;
                 in9[HT][0] = Mode::template to_act<false>(e2);
-                IO::store(tile_ptr<Mode>(P, 2 * n + 4, st, 0, lane), in9[HT][0]);
+                IO::store_g(tile_ptr<Mode>(P, 2 * n + 4, st, 0, lane), in9[HT][0]);
             }
             dense<Mode, 1, HT / 4, 1>(pipe, zero_bias, h, G, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, d1, 2 * n + 7); });
             mcur = mnext;
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v2_kernel(const Tra
             dense<Mode, HT / 2, HT, 1>(pipe, zero_bias, h, d0, [&](auto m_, f32x16(&acc)[1]) {          // d feature_vec: no activation to undo
                 constexpr int m = decltype(m_)::value;
                 in9[m][0] = Mode::template to_act<false>(acc[0]);
-                IO::store(tile_ptr<Mode>(P, 2 * n + 5, st, m, lane), in9[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, 2 * n + 5, st, m, lane), in9[m][0]);
             });
         }
         Act A[HT][1], B[HT][1];

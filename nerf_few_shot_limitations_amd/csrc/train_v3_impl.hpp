@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v3_kernel(const Trai
                 x[PT + t][0] = Mode::template to_act<false>(e);
             }
 #pragma unroll
-            for (int t = 0; t < KT0; ++t) IO::store(tile_ptr<Mode>(P, slot, st, t, lane), x[t][0]);
+            for (int t = 0; t < KT0; ++t) IO::store_g(tile_ptr<Mode>(P, slot, st, t, lane), x[t][0]);
         };
         // Linear + ReLU with saved output (slot) and ReLU bits (plane)
         auto relu_layer = [&](const auto& in, auto& out, auto kt_, auto mt_, int slot, int plane, int boff) {
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v3_kernel(const Trai
                 out[m][0] = Mode::template to_act<true>(acc[0]);
                 __builtin_amdgcn_sched_barrier(0);   // relu_bits is inline asm: it must come after a compiler-visible read of the accumulators (MFMA -> VALU hazard)
                 put_bits<m>(mw, relu_bits(acc[0]));
-                IO::store(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, slot, st, m, lane), out[m][0]);
                 if constexpr (m == MT - 1) *mask_ptr(P, plane, st, lane) = mw;
             });
         };
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v3_kernel(const Trai
         dense<Mode, HT, HT, 1>(pipe, bias + boff, h, B, [&](auto m_, f32x16(&acc)[1]) {          // output_proj: no activation
             constexpr int m = decltype(m_)::value;
             A[m][0] = Mode::template to_act<false>(acc[0]);
-            IO::store(tile_ptr<Mode>(P, 7, st, m, lane), A[m][0]);
+            IO::store_g(tile_ptr<Mode>(P, 7, st, m, lane), A[m][0]);
         });
         boff += 32 * HT;
 
@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v3_kernel(const Trai
             dense<Mode, HT, HT, 1>(pipe, bias + tb + 32, h, X, [&](auto m_, f32x16(&acc)[1]) {     // feature_head: no activation
                 constexpr int m = decltype(m_)::value;
                 in9[m][0] = Mode::template to_act<false>(acc[0]);
-                IO::store(tile_ptr<Mode>(P, 8 + n, st, m, lane), in9[m][0]);
+                IO::store_g(tile_ptr<Mode>(P, 8 + n, st, m, lane), in9[m][0]);
             });
             {
                 float dd[3];
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_forward_v3_kernel(const Trai
                 Act t1[pe_tiles(LD)];
                 encode3<Mode, LD>(dd, h, t1);
                 in9[HT][0] = t1[0];
-                IO::store(tile_ptr<Mode>(P, 8 + n, st, HT, lane), t1[0]);
+                IO::store_g(tile_ptr<Mode>(P, 8 + n, st, HT, lane), t1[0]);
             }
             Act c0[HT / 2][1], c1[HT / 4][1];
             relu_layer(in9, c0, std::integral_constant<int, HT + 1>{}, std::integral_constant<int, HT / 2>{}, 9 + n, 5 + n, tb + 32 + 32 * HT);
@@ -234,13 +234,13 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v3_kernel(const Tra
         auto masked = [&](auto m_, f32x16(&acc)[1], auto& out, int slot_dz) {
             constexpr int m = decltype(m_)::value;
             out[m][0] = masked_act<Mode, m>(acc[0], mcur);
-            IO::store(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
+            IO::store_g(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
         };
         // dZ = dH (the layer had no activation)
         auto plain = [&](auto m_, f32x16(&acc)[1], auto& out, int slot_dz) {
             constexpr int m = decltype(m_)::value;
             out[m][0] = Mode::template to_act<false>(acc[0]);
-            IO::store(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
+            IO::store_g(tile_ptr<Mode>(P, slot_dz, st, m, lane), out[m][0]);
         };
 
         Act in9[HT + 1][1];
@@ -258,11 +258,11 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v3_kernel(const Tra
                     ds = P.density[raw] > 0.0f ? P.g_density[raw] : 0.0f;
                 }
                 G[0][0] = Mode::template to_act<false>(e);
-                IO::store(tile_ptr<Mode>(P, D + 11 + n, st, 0, lane), G[0][0]);
+                IO::store_g(tile_ptr<Mode>(P, D + 11 + n, st, 0, lane), G[0][0]);
                 f32x16 e2 = {};
                 e2[0] = ds;
                 in9[HT][0] = Mode::template to_act<false>(e2);
-                IO::store(tile_ptr<Mode>(P, D + 7 + n, st, 0, lane), in9[HT][0]);
+                IO::store_g(tile_ptr<Mode>(P, D + 7 + n, st, 0, lane), in9[HT][0]);
             }
             dense<Mode, 1, HT / 4, 1>(pipe, zero_bias, h, G, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, d1, D + 10 + n); });
             mcur = mnext;
@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v3_kernel(const Tra
             float dw0 = 0.0f, dw1 = 0.0f;
             dense<Mode, HT, KT0, 1>(pipe, zero_bias, h, Y, [&](auto m_, f32x16(&acc)[1]) {
                 constexpr int m = decltype(m_)::value;
-                const f32x16 xin = ActF32<Mode>::get(IO::template load<Act>(tile_ptr<Mode>(P, 0, st, m, lane)));
+                const f32x16 xin = ActF32<Mode>::get(IO::template load_g<Act>(tile_ptr<Mode>(P, 0, st, m, lane)));
                 float s = 0.0f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s = __builtin_fmaf(acc[0][r], xin[r], s);
@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(WAVES * 64) train_backward_v3_kernel(const Tra
                 f32x16 e = {};
                 if (h == 0) { e[0] = w.x * (dw0 - s); e[1] = w.y * (dw1 - s); }
                 G2[0][0] = Mode::template to_act<false>(e);
-                IO::store(tile_ptr<Mode>(P, D + 3, st, 0, lane), G2[0][0]);
+                IO::store_g(tile_ptr<Mode>(P, D + 3, st, 0, lane), G2[0][0]);
             }
             mcur = *mask_ptr(P, 2, st, lane);
             dense<Mode, 1, HT / 4, 1>(pipe, zero_bias, h, G2, [&](auto m_, f32x16(&acc)[1]) { masked(m_, acc, da0, D + 2); });   // attention.2^T

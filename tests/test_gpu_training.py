@@ -991,6 +991,31 @@ def test_composite_mse_backward_equals_the_three_calls(N, R, S, opaque, white, p
 
 
 @pytest.mark.parametrize("mode", ["bf16", "f32"])
+def test_forward_train_input_rows_aligned_or_not_ragged_or_not(N, mode):
+    """The input rows of the training forward may start anywhere a float may (a row-offset view of a larger tensor: 4-byte aligned
+    only) and the batch may end anywhere in a tile: the same outputs and the same gradients, bit for bit, as from a fresh allocation.
+    (Written with a variant of train_forward_kernel that staged whole tiles through LDS with 16-byte loads when it could -- measured
+    no faster, not kept; the property is what callers rely on.)"""
+    m, _ = make_model(N, mode, scene="solid")
+    m.train()
+    for n in (1, 31, 32, 33, 255, 256, 257, 1000):
+        big = torch.from_numpy(O.uniform01(700 + n, (n + 1) * 63).reshape(n + 1, 63) * 2 - 1).float().cuda()
+        xa = big[1:].clone()                                # fresh allocation: 256-byte aligned
+        xu = big[1:]                                        # 252 bytes into an allocation: 4-byte aligned only
+        assert xa.data_ptr() % 16 == 0 and xu.data_ptr() % 16 != 0 and xu.is_contiguous()
+        g = torch.from_numpy(O.uniform01(800 + n, n * 4).reshape(n, 4) - 0.5).float().cuda()
+        outs, grads = [], []
+        for x in (xa, xu):
+            m.zero_grad(set_to_none=True)
+            out = m(x)
+            (out * g).sum().backward()
+            outs.append(out.detach().clone())
+            grads.append(torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone())
+        assert torch.equal(outs[0], outs[1]), n
+        assert torch.equal(grads[0], grads[1]), n
+
+
+@pytest.mark.parametrize("mode", ["bf16", "f32"])
 def test_gradient_is_additive_over_the_batch_at_scale(N, mode):
     """Size-independent property at a batch no CPU check could cover (131 072 samples, 8-wave kernels in bf16): every
     sample's chain is independent of its neighbours, so grad(batch) = grad(first half) + grad(second half) up to fp32

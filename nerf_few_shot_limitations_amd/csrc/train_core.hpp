@@ -33,6 +33,9 @@ struct ActIO16 {
     // stores -7.7 % of the step, loads another -3 %; profiles/r03_ab_train_nontemporal.txt)
     template <class Act>
     __device__ static __forceinline__ void store_g(char* p, const Act& a) {
+#ifdef NRF_TRAIN_NO_STORE          // timing experiment only (results are wrong): what the chain kernels cost without their stores
+        if (p == nullptr)
+#endif
 #pragma unroll
         for (int v = 0; v < 2; ++v) __builtin_nontemporal_store(__builtin_bit_cast(i32x4, a.f[v]), (i32x4*)(p + v * kFragBytes));
     }

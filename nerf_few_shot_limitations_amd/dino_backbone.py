@@ -17,7 +17,6 @@ image quality is not -- lego PSNR parity of the DINO variants stays unpinned.
 """
 from __future__ import annotations
 
-import math
 import os
 import warnings
 from types import SimpleNamespace

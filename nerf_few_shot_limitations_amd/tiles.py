@@ -16,7 +16,6 @@ from typing import Optional
 import torch
 
 from . import _lib as L
-from .ray_sampler import _c2w12
 
 
 def tile_plan(n_rays: int, world: int, tile_rays: int):

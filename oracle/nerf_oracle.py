@@ -25,7 +25,7 @@ All arithmetic is fp32, like the reference.
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Tuple
+from typing import Dict
 
 import numpy as np
 import torch

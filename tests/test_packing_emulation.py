@@ -249,6 +249,29 @@ def test_out_rgbd_rows_must_be_16_byte_aligned(L):
     assert b"model is NULL" in lib.nrf_last_error()
 
 
+def test_fused_step_entry_points_refuse_bad_arguments_before_any_launch(L):
+    """nrf_composite_mse_backward / nrf_adam_step_loss (ABI v5): sizes, strides and the pointers they need are checked on the host
+    (no GPU needed: nothing is launched)."""
+    lib = L.lib()
+    P = lambda a: C.c_void_p(a)
+    ok = dict(rgb=P(0x1000), rs=4, sig=P(0x100C), ss=4, z=P(0x2000), d=P(0x3000), R=8, S=16, white=0, tgt=P(0x4000), w=1.0, pred=None,
+              drgb=P(0x5000), drs=4, dsig=P(0x500C), dss=4, rl=P(0x6000), zb=None, zn=0)
+
+    def call(**kw):
+        a = dict(ok, **kw)
+        return lib.nrf_composite_mse_backward(a["rgb"], a["rs"], a["sig"], a["ss"], a["z"], a["d"], a["R"], a["S"], a["white"], a["tgt"], a["w"],
+                                              a["pred"], a["drgb"], a["drs"], a["dsig"], a["dss"], a["rl"], a["zb"], a["zn"], None)
+    for bad in (dict(R=0), dict(R=-3), dict(S=0), dict(S=5000), dict(rs=2), dict(ss=0), dict(drs=1), dict(dss=0), dict(rgb=None), dict(sig=None),
+                dict(z=None), dict(d=None), dict(tgt=None), dict(drgb=None), dict(dsig=None), dict(rl=None), dict(zn=-1), dict(zn=4)):
+        assert call(**bad) == -1, bad
+        assert lib.nrf_last_error()
+    adam = lambda **kw: lib.nrf_adam_step_loss(kw.get("p", P(0x1000)), kw.get("g", P(0x2000)), kw.get("m", P(0x3000)), kw.get("v", P(0x4000)),
+                                               kw.get("n", 100), 1e-3, kw.get("b1", 0.9), 0.999, 1e-8, 0.0, kw.get("step", 1), kw.get("rl", P(0x5000)),
+                                               kw.get("R", 8), 1.0, kw.get("loss", P(0x6000)), None)
+    for bad in (dict(n=0), dict(step=0), dict(p=None), dict(g=None), dict(m=None), dict(v=None), dict(b1=1.0), dict(rl=None), dict(loss=None), dict(R=0)):
+        assert adam(**bad) == -1, bad
+
+
 @pytest.mark.parametrize("mode", ["f16", "f16x3"])
 def test_f16_typed_streams_saturate_instead_of_overflowing(L, mode):
     """a weight beyond the f16 range used to pack as inf (split mode: hi = inf, lo = -inf -> NaN products).  The packer

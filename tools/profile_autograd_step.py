@@ -30,7 +30,8 @@ def main():
     if a.net == "v1":
         m = N.NeRFMLP(pos_dim=63, hidden_dim=256, n_layers=8, mma_mode=a.mode)
     else:
-        m = N.NeRFMLP(pos_freq_bands=10, dir_freq_bands=4, hidden_dim=256, n_layers=8, use_dino=a.net == "v3", dino_dim=64, mma_mode=a.mode)
+        m = N.NeRFMLP(pos_freq=12 if a.net == "v3" else 10, dir_freq=4, hidden_dim=256, num_density_layers=8, use_dino=a.net == "v3", dino_dim=64,
+                      mma_mode=a.mode)
     m = m.to(dev).train()
     R, S = a.rays, a.samples
     rend = N.NeRFRenderer(m, 2.0, 6.0, dino_features=[torch.rand(1, 9, 9, 64, device=dev) * 2 - 1] if a.net == "v3" else None,

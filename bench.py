@@ -98,14 +98,14 @@ def training_line(N, args, dev):
         loss = step(pts, z, d, tgt, **kw)
         first = loss.item() if first is None else first
     torch.cuda.synchronize()
-    k = 50
+    k = 200        # long enough to leave the first dozens of steps after a pause behind (they run 10-15 % faster: the chip's power state)
     t0 = time.perf_counter()
     for _ in range(k):
         loss = step(pts, z, d, tgt, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / k
     out = {"metric": "M ray-samples/s per optimisation step (forward + backward + Adam)", "value": round(R * S / dt / 1e6, 2),
-           "ms_per_step": round(dt * 1e3, 4), "rays": R, "samples_per_ray": S, "net": args.net, "dtype": mode,
+           "ms_per_step": round(dt * 1e3, 4), "steps_timed": k, "rays": R, "samples_per_ray": S, "net": args.net, "dtype": mode,
            "loss_first": round(first, 6), "loss_last": round(loss.item(), 6)}
     # the reference's UNMODIFIED train_step body (train.py:280-287) on the drop-in surface: render_rays with a grad_fn, torch's own Adam
     rend = N.NeRFRenderer(m, 2.0, 6.0, dino_features=[torch.rand(1, 9, 9, 64, device=dev) * 2 - 1] if args.net == "v3" else None,
